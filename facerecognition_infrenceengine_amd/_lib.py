@@ -1,0 +1,102 @@
+"""ctypes binding of libfrhip.so (include/frhip.h).  No CPU fallback: a missing library
+or a failing call raises."""
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfrhip.so")
+
+_lock = threading.Lock()
+_lib = None
+
+
+class FrError(RuntimeError):
+    pass
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p),
+                ("bias", C.c_void_p), ("slope", C.c_void_p), ("residual", C.c_void_p),
+                ("out_f32_partial", C.c_void_p),
+                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
+                ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
+                ("Ho", C.c_int), ("Wo", C.c_int), ("bias_mode", C.c_int), ("splitk", C.c_int)]
+
+
+_P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/frhip.h declares
+SIGNATURES = {
+    "fr_version": (_I, []),
+    "fr_last_error_string": (C.c_char_p, []),
+    "fr_device_count": (_I, []),
+    "fr_l2norm_rows_f32": (_I, [_P, _P, _I, _I, _P]),
+    "fr_gallery_match_workspace": (_Z, [_I, _L]),
+    "fr_gallery_match_f32": (_I, [_P, _P, _I, _L, _I, _L, _P, _P, _P, _Z, _P]),
+    "fr_f32_to_f16": (_I, [_P, _P, _L, _P]),
+    "fr_match_decide": (_I, [_P, _P, _I, _F, _F, _P, _P]),
+}
+
+_NOCHECK = ("fr_version", "fr_device_count")
+
+
+class Lib:
+    """Thin checked wrapper: ``lib.fr_xxx(...)`` raises FrError on a negative return."""
+
+    def __init__(self, cdll):
+        self._c = cdll
+        self._calls = {}
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(cdll, name)      # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+            if res is _I and name not in _NOCHECK:
+                self._calls[name] = self._checked(name, fn)
+            else:
+                self._calls[name] = fn
+
+    def _checked(self, name, fn):
+        err = self._c.fr_last_error_string
+
+        def call(*a):
+            rc = fn(*a)
+            if rc != 0:
+                raise FrError(f"{name} failed ({rc}): {err().decode()}")
+            return rc
+        return call
+
+    def __getattr__(self, name):
+        try:
+            return self.__dict__["_calls"][name]
+        except KeyError:
+            raise AttributeError(name)
+
+
+def load():
+    """Load the in-tree libfrhip.so.  Raises FrError if it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise FrError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              f"or `make -C {os.path.dirname(LIB_PATH)}`; there is no CPU fallback")
+            _lib = Lib(C.CDLL(LIB_PATH))
+        return _lib
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    """The current torch HIP stream as a void*."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise FrError("no HIP device visible: this engine has no CPU path")

@@ -1,0 +1,210 @@
+// Gallery match: re-normalise, linear scan with strict-'>' first-max, decision.
+// Replaces the Python loop at /root/reference/infrenceServer.py:530-552.
+//
+// f32 scan: scores are computed on the f32 MFMA (v_mfma_f32_32x32x2_f32 is an exact
+// k-ordered fmaf chain, so scores are plain IEEE f32 dot products).  Orientation:
+// A = 32 gallery rows, B = 32 queries, so a lane owns ONE query (column) and 16 gallery
+// rows (registers): the running (max, first-argmax) is lane-local, no cross-lane work
+// inside the scan.  HBM-bound: N*D*4 bytes per pass per 32-query group.
+#include "common.h"
+
+#define GD 512          // embedding dim
+#define QPAD 516        // LDS row stride (floats) for the query tile: breaks the 2 KB bank stride
+#define QG 32           // queries per group (MFMA N)
+
+struct BestPair { float s; int64_t i; };
+
+__device__ __forceinline__ void take_better(float& bs, int64_t& bi, float s, int64_t i) {
+    // max score; lowest index on exact ties (== first maximum in row order)
+    if (s > bs || (s == bs && i < bi && i >= 0)) { bs = s; bi = i; }
+}
+
+__global__ __launch_bounds__(256) void gallery_scan_f32(const float* __restrict__ Q, const float* __restrict__ G,
+                                                        int F, int64_t N, float* __restrict__ ws_score,
+                                                        int64_t* __restrict__ ws_idx) {
+    __shared__ __attribute__((aligned(16))) float qs[QG * QPAD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q0 = blockIdx.y * QG;
+    // stage the query group (zero rows beyond F)
+    for (int e = tid; e < QG * (GD / 4); e += 256) {
+        int r = e / (GD / 4), c = e % (GD / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q0 + r < F) v = *reinterpret_cast<const float4*>(Q + (int64_t)(q0 + r) * GD + c * 4);
+        *reinterpret_cast<float4*>(&qs[r * QPAD + c * 4]) = v;
+    }
+    __syncthreads();
+    const int r = lane & 31, h = lane >> 5;
+    float best = -INFINITY;
+    int64_t besti = -1;
+    const int64_t ntiles = (N + 31) / 32;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
+        const int64_t row = t * 32 + r;
+        const bool ok = row < N;
+        const float* gp = G + (ok ? row : 0) * GD + 4 * h;
+        const float* qp = &qs[r * QPAD + 4 * h];
+        float16v acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int kk = 0; kk < GD / 8; ++kk) {
+            float4 a = *reinterpret_cast<const float4*>(gp + kk * 8);
+            float4 b = *reinterpret_cast<const float4*>(qp + kk * 8);
+            if (!ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+        // acc[reg] = score(gallery row t*32 + (reg&3) + 8*(reg>>2) + 4*h, query q0 + r)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            int64_t gi = t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            float s = acc[reg];
+            if (gi < N && s > best) { best = s; besti = gi; }   // rows ascend within a lane
+        }
+    }
+    // merge the two half-waves that hold the same query, then the 4 waves through LDS
+    {
+        float os = __shfl_xor(best, 32, 64);
+        int64_t oi = __shfl_xor(besti, 32, 64);
+        if (oi >= 0) take_better(best, besti, os, oi);
+    }
+    __syncthreads();
+    float* ls = qs;                                   // reuse LDS
+    int64_t* li = reinterpret_cast<int64_t*>(qs + 256);
+    if (h == 0) { ls[wave * 32 + r] = best; li[wave * 32 + r] = besti; }
+    __syncthreads();
+    if (tid < 32) {
+        float bs = ls[tid]; int64_t bi = li[tid];
+        for (int w = 1; w < 4; ++w) if (li[w * 32 + tid] >= 0) take_better(bs, bi, ls[w * 32 + tid], li[w * 32 + tid]);
+        if (q0 + tid < F) {
+            ws_score[(int64_t)blockIdx.x * F + q0 + tid] = bs;
+            ws_idx[(int64_t)blockIdx.x * F + q0 + tid] = bi;
+        }
+    }
+}
+
+__global__ void gallery_reduce(const float* __restrict__ ws_score, const int64_t* __restrict__ ws_idx, int nblk,
+                               int F, int64_t row_offset, int64_t* __restrict__ out_idx,
+                               float* __restrict__ out_score) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    float bs = -INFINITY; int64_t bi = -1;
+    for (int b = 0; b < nblk; ++b) {
+        int64_t i = ws_idx[(int64_t)b * F + f];
+        if (i >= 0) take_better(bs, bi, ws_score[(int64_t)b * F + f], i);
+    }
+    // reference: best_score starts at -1 and only a strictly larger score replaces it
+    if (bi < 0 || !(bs > -1.0f)) { out_idx[f] = -1; out_score[f] = -1.0f; }
+    else { out_idx[f] = bi + row_offset; out_score[f] = bs; }
+}
+
+static int scan_blocks(int64_t N) {
+    int64_t tiles = (N + 31) / 32;
+    int64_t b = (tiles + 3) / 4;
+    if (b < 1) b = 1;
+    if (b > 1024) b = 1024;
+    return (int)b;
+}
+
+extern "C" size_t fr_gallery_match_workspace(int F, int64_t N) {
+    size_t per = (size_t)scan_blocks(N) * (size_t)(F > 0 ? F : 1);
+    return per * (sizeof(float) + sizeof(int64_t)) + 512;
+}
+
+extern "C" int fr_gallery_match_f32(const float* Q, const float* G, int F, int64_t N, int D, int64_t row_offset,
+                                    int64_t* out_idx, float* out_score, void* workspace, size_t workspace_bytes,
+                                    fr_stream_t stream) {
+    FR_REQUIRE(D == GD, "fr_gallery_match_f32: D must be %d (got %d)", GD, D);
+    FR_REQUIRE(F >= 0 && N >= 0, "fr_gallery_match_f32: negative size");
+    if (F == 0) return FR_OK;
+    FR_REQUIRE(Q && out_idx && out_score && (G || N == 0), "fr_gallery_match_f32: null pointer");
+    FR_REQUIRE(workspace && workspace_bytes >= fr_gallery_match_workspace(F, N),
+               "fr_gallery_match_f32: workspace too small (%zu < %zu)", workspace_bytes,
+               fr_gallery_match_workspace(F, N));
+    const int nblk = scan_blocks(N);
+    float* ws_score = reinterpret_cast<float*>(workspace);
+    size_t off = ((size_t)nblk * F * sizeof(float) + 255) & ~(size_t)255;
+    int64_t* ws_idx = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(workspace) + off);
+    hipStream_t s = fr_stream(stream);
+    dim3 grid(nblk, (F + QG - 1) / QG);
+    gallery_scan_f32<<<grid, 256, 0, s>>>(Q, G, F, N, ws_score, ws_idx);
+    FR_CHECK_LAUNCH("gallery_scan_f32");
+    gallery_reduce<<<fr_cdiv(F, 64), 64, 0, s>>>(ws_score, ws_idx, nblk, F, row_offset, out_idx, out_score);
+    FR_CHECK_LAUNCH("gallery_reduce");
+    return FR_OK;
+}
+
+// ---------------------------------------------------------------- l2norm rows
+__global__ void l2norm_rows(const float* __restrict__ x, float* __restrict__ out, int rows, int dim) {
+    int row = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* p = x + (int64_t)row * dim;
+    float ss = 0.f;
+    for (int c = lane * 4; c < dim; c += 256) {
+        float4 v = *reinterpret_cast<const float4*>(p + c);
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    ss = wave_sum(ss);
+    float nrm = sqrtf(ss);
+    for (int c = lane * 4; c < dim; c += 256) {
+        float4 v = *reinterpret_cast<const float4*>(p + c);
+        v.x /= nrm; v.y /= nrm; v.z /= nrm; v.w /= nrm;
+        *reinterpret_cast<float4*>(out + (int64_t)row * dim + c) = v;
+    }
+}
+
+extern "C" int fr_l2norm_rows_f32(const float* x, float* out, int rows, int dim, fr_stream_t stream) {
+    FR_REQUIRE(rows >= 0 && dim > 0 && dim % 4 == 0, "fr_l2norm_rows_f32: dim must be a positive multiple of 4");
+    if (rows == 0) return FR_OK;
+    FR_REQUIRE(x && out, "fr_l2norm_rows_f32: null pointer");
+    l2norm_rows<<<fr_cdiv(rows, 4), 256, 0, fr_stream(stream)>>>(x, out, rows, dim);
+    FR_CHECK_LAUNCH("l2norm_rows");
+    return FR_OK;
+}
+
+// ---------------------------------------------------------------- decision
+__global__ void match_decide(const int64_t* idx, const float* score, int F, float thr, float unknown_thr,
+                             int32_t* decision) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    bool has = idx[f] >= 0;
+    float s = score[f];
+    int d;
+    if (has && s >= thr) d = 1;
+    else if (s < unknown_thr) d = 0;
+    else d = 2;
+    decision[f] = d;
+}
+
+extern "C" int fr_match_decide(const int64_t* idx, const float* score, int F, float thr, float unknown_thr,
+                               int32_t* decision, fr_stream_t stream) {
+    if (F <= 0) return FR_OK;
+    FR_REQUIRE(idx && score && decision, "fr_match_decide: null pointer");
+    match_decide<<<fr_cdiv(F, 256), 256, 0, fr_stream(stream)>>>(idx, score, F, thr, unknown_thr, decision);
+    FR_CHECK_LAUNCH("match_decide");
+    return FR_OK;
+}
+
+__global__ void f32_to_f16_k(const float* __restrict__ x, half_t* __restrict__ out, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    for (; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        if (i + 3 < n) {
+            float4 v = *reinterpret_cast<const float4*>(x + i);
+            half4 o = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+            *reinterpret_cast<half4*>(out + i) = o;
+        } else {
+            for (int64_t j = i; j < n; ++j) out[j] = (half_t)x[j];
+        }
+    }
+}
+
+extern "C" int fr_f32_to_f16(const float* x, void* out, int64_t n, fr_stream_t stream) {
+    if (n <= 0) return FR_OK;
+    FR_REQUIRE(x && out, "fr_f32_to_f16: null pointer");
+    int blocks = (int)((n / 4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    f32_to_f16_k<<<blocks, 256, 0, fr_stream(stream)>>>(x, reinterpret_cast<half_t*>(out), n);
+    FR_CHECK_LAUNCH("f32_to_f16");
+    return FR_OK;
+}

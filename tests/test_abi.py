@@ -1,0 +1,40 @@
+"""The C-ABI library loads and exports every symbol include/frhip.h declares (no GPU needed)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "frhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    from facerecognition_infrenceengine_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    cdll = ctypes.CDLL(_lib.LIB_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 8
+    for s in syms:
+        assert hasattr(cdll, s), f"{s} declared in frhip.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
+    for s in _lib.SIGNATURES:
+        assert s in syms, f"{s} bound but not declared in frhip.h"
+    lib = _lib.load()
+    assert lib.fr_version() >= 100
+
+
+def test_invalid_arguments_return_error_not_crash():
+    from facerecognition_infrenceengine_amd import _lib
+    lib = _lib.load()
+    with pytest.raises(_lib.FrError, match="D must be 512"):
+        lib.fr_gallery_match_f32(None, None, 1, 10, 256, 0, None, None, None, 0, None)
+    with pytest.raises(_lib.FrError):
+        lib.fr_l2norm_rows_f32(None, None, 4, 7, None)

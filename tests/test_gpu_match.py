@@ -1,0 +1,82 @@
+"""GPU parity: gallery match through the C ABI vs the reference-pinned oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import match as omatch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def matcher():
+    from facerecognition_infrenceengine_amd.gallery import GalleryMatcher
+    return GalleryMatcher("cuda:0")
+
+
+@pytest.mark.parametrize("tag", ["g100", "g1000"])
+def test_match_golden_ids_and_decisions(matcher, golden, tag):
+    d = golden("match_kat.npz")
+    G, Q = d[f"{tag}_G"], d[f"{tag}_Q"]
+    matcher.set_rows(list(range(len(G))), G, normalise=False)
+    ids, score, idx = matcher.match(Q, thr=0.4)
+    exp = d[f"{tag}_live_pid"]
+    got = np.asarray([-1 if i is None else i for i in ids])
+    assert np.array_equal(got, exp)                      # identical top-1 ids + >= 0.4 decisions
+    oi, os_ = omatch.match_rows(Q, G)
+    assert np.array_equal(idx, oi)
+    np.testing.assert_allclose(score, os_, atol=2e-6)    # f32 dot, different summation order
+    assert idx[2] == 17                                   # exact tie 17/63 -> lowest row
+    # counting-path band (peopleCount.py:876-887)
+    ids2, _, _ = matcher.match(Q, thr=0.45, unknown_thr=0.35)
+    rec = [i for i in ids2 if i is not None]
+    assert rec == list(d[f"{tag}_count_rec_pid"])
+
+
+def test_l2norm_rows_matches_numpy(lib):
+    from facerecognition_infrenceengine_amd import _lib
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal((37, 512)) * 3).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    out = torch.empty_like(xd)
+    lib.fr_l2norm_rows_f32(_lib.ptr(xd), _lib.ptr(out), 37, 512, _lib.stream_ptr())
+    ref = x / np.linalg.norm(x, axis=1, keepdims=True)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=3e-7, atol=1e-8)
+
+
+@pytest.mark.parametrize("N,F", [(0, 3), (1, 1), (31, 5), (33, 40), (4097, 70), (10000, 256)])
+def test_match_ragged_sizes(matcher, N, F):
+    rng = np.random.default_rng(N + F)
+    G = rng.standard_normal((N, 512)).astype(np.float32)
+    if N:
+        G /= np.linalg.norm(G, axis=1, keepdims=True)
+    Q = rng.standard_normal((F, 512)).astype(np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    if N > 3:
+        G[N - 1] = Q[0]; G[N // 2] = Q[0]                 # duplicate rows: lowest index wins
+    matcher.set_rows(list(range(N)), G, normalise=False)
+    idx, score = matcher.match_device(torch.from_numpy(Q).cuda())
+    idx, score = idx.cpu().numpy(), score.cpu().numpy()
+    if N == 0:
+        assert (idx == -1).all() and (score == -1).all()
+        return
+    oi, os_ = omatch.match_rows_fast(Q, G)
+    assert np.array_equal(idx, oi)
+    np.testing.assert_allclose(score, os_, atol=3e-6)
+    if N > 3:
+        assert idx[0] == N // 2
+
+
+def test_full_size_property_planted_rows(matcher):
+    """BASELINE config sizes (10k and 1M rows): every query has a planted row; ids must be
+    exactly the planted rows (size-independent property, no CPU oracle at this size)."""
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for N in (10_000, 1_000_000):
+        G = torch.randn((N, 512), generator=g, device="cuda")
+        G /= G.norm(dim=1, keepdim=True)
+        rows = torch.randperm(N, generator=g, device="cuda")[:256]
+        Q = G[rows] + 0.02 * torch.randn((256, 512), generator=g, device="cuda")
+        matcher.set_rows(range(N), G, normalise=False)
+        idx, score = matcher.match_device(Q)
+        assert torch.equal(idx, rows)
+        assert float(score.min()) > 0.8
