@@ -36,6 +36,8 @@ SIGNATURES = {
     "fr_gallery_match_f32": (_I, [_P, _P, _I, _L, _I, _L, _P, _P, _P, _Z, _P]),
     "fr_f32_to_f16": (_I, [_P, _P, _L, _P]),
     "fr_match_decide": (_I, [_P, _P, _I, _F, _F, _P, _P]),
+    "fr_conv_nhwc_f16": (_I, [C.POINTER(ConvArgs), _P]),
+    "fr_fc_reduce_l2norm": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
 }
 
 _NOCHECK = ("fr_version", "fr_device_count")
@@ -78,6 +80,9 @@ def load():
     global _lib
     with _lock:
         if _lib is None:
+            # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's): import it first so
+            # this process has ONE HIP runtime, shared by torch's allocator/streams and our kernels
+            import torch  # noqa: F401
             if not os.path.exists(LIB_PATH):
                 raise FrError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               f"or `make -C {os.path.dirname(LIB_PATH)}`; there is no CPU fallback")

@@ -1,0 +1,281 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores: NHWC f16 activations, f32 accumulate,
+// fused (bias | border-class bias) + PReLU + residual epilogue, or split-K f32 partials (FC).
+// This is the ArcFace IResNet conv stack that the reference runs inside
+// FaceAnalysis.get (/root/reference/infrenceServer.py:528) through ONNX Runtime.
+//
+// GEMM view:  C[cout][pixel] = sum_k W[cout][k] * X[pixel][k],  k = (kh*KW + kw)*Cin + ci.
+//   MFMA A operand = weights (rows = couts), B operand = gathered input pixels (cols = pixels):
+//   with v_mfma_f32_16x16x32_f16 a lane then owns ONE pixel and 4 CONSECUTIVE couts per
+//   accumulator quad, i.e. 8 contiguous bytes of the NHWC output row.
+// Tiling: 256 threads = 4 waves, each wave 64 couts x 64 pixels (4x4 MFMA tiles, 64 acc VGPRs);
+//   block = (64*WN couts) x (64*(4/WN) pixels); K step 64 (always inside one filter tap when
+//   Cin >= 64); two LDS stages, register-prefetched (global->VGPR issued before the MFMAs of the
+//   current stage, VGPR->LDS after them), one barrier per K step.
+// LDS image: rows of 64 halves (128 B), 16-B chunk index XOR (row & 7): conflict-free for the
+//   ds_read_b128 fragment reads of the 16x16x32 operand layout.
+// Zero padding / M tail: buffer loads with the offset forced out of range return 0.
+#include "common.h"
+
+#define BK 64
+
+struct ConvP {
+    const half_t* x; const half_t* w; half_t* y;
+    const float* bias; const float* slope; const half_t* res; float* partial;
+    int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, bias_mode, splitk;
+    int M, K, nk;            // M = B*Ho*Wo, K = row length of w (halves), nk = K / 64
+    unsigned xbytes, wbytes;
+};
+
+__device__ __forceinline__ int4v buf_load16(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+}
+
+template <int WN, bool SMALL_CIN>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
+    constexpr int WP = 4 / WN;
+    constexpr int BN = 64 * WN;      // couts per block
+    constexpr int BM = 64 * WP;      // pixels per block
+    constexpr int WROWS = BN / 32;   // 16-B chunk rows per thread (weights)
+    constexpr int XROWS = BM / 32;
+    __shared__ __attribute__((aligned(16))) half_t lds[2 * (BN + BM) * BK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave % WN, wp = wave / WN;
+    const int cout0 = blockIdx.y * BN;
+    const int m0 = blockIdx.x * BM;
+    const int trow = tid >> 3, tchunk = tid & 7;
+
+    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
+
+    // ---- per-thread gather state for its XROWS pixels
+    int xbase[XROWS];   // byte offset of (n, ho*s-pad, wo*s-pad, chunk*8)
+    int xhw[XROWS];     // (base_h << 16) | (base_w & 0xffff); base_h = -32768 marks an invalid row
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < XROWS; ++i) {
+        int m = m0 + trow + 32 * i;
+        if (m < p.M) {
+            int n = m / HoWo, r = m - n * HoWo;
+            int ho = r / p.Wo, wo = r - ho * p.Wo;
+            int bh = ho * p.stride - p.pad, bw = wo * p.stride - p.pad;
+            xbase[i] = (((n * p.H + bh) * p.W + bw) * p.Cin + (SMALL_CIN ? 0 : tchunk * 8)) * 2;
+            xhw[i] = (bh << 16) | (bw & 0xffff);
+        } else {
+            xbase[i] = 0;
+            xhw[i] = (int)0x80000000u;
+        }
+    }
+    unsigned wbase[WROWS];
+#pragma unroll
+    for (int i = 0; i < WROWS; ++i) wbase[i] = ((unsigned)(cout0 + trow + 32 * i) * p.K + tchunk * 8) * 2;
+
+    // K range of this block (split-K over blockIdx.z)
+    int ks = 0, ke = p.nk;
+    if (p.splitk > 1) {
+        int per = (p.nk + p.splitk - 1) / p.splitk;
+        ks = blockIdx.z * per;
+        ke = min(p.nk, ks + per);
+    }
+
+    int4v wreg[WROWS], xreg[XROWS];
+    const int cin_steps = SMALL_CIN ? 1 : (p.Cin / BK);
+
+    auto gload = [&](int s) {
+        int kh, kw, tapoff;
+        if (SMALL_CIN) {
+            int tap = s * 8 + tchunk;              // one 16-B chunk (8 padded channels) per tap
+            kh = tap / p.KW; kw = tap - kh * p.KW;
+            if (tap >= p.KH * p.KW) kh = 1 << 14;  // beyond the filter: force out of range
+            tapoff = (kh * p.W + kw) * p.Cin * 2;
+        } else {
+            int tap = s / cin_steps, c0 = (s - tap * cin_steps) * BK;
+            kh = tap / p.KW; kw = tap - kh * p.KW;
+            tapoff = ((kh * p.W + kw) * p.Cin + c0) * 2;
+        }
+#pragma unroll
+        for (int i = 0; i < WROWS; ++i) wreg[i] = buf_load16(wrs, wbase[i] + (unsigned)s * (BK * 2));
+#pragma unroll
+        for (int i = 0; i < XROWS; ++i) {
+            int hi = (xhw[i] >> 16) + kh, wi = (int)(short)(xhw[i] & 0xffff) + kw;
+            bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            unsigned off = ok ? (unsigned)(xbase[i] + tapoff) : 0x80000000u;
+            xreg[i] = buf_load16(xrs, off);
+        }
+    };
+    auto lstore = [&](int buf) {
+        half_t* wl = lds + buf * (BN + BM) * BK;
+        half_t* xl = wl + BN * BK;
+#pragma unroll
+        for (int i = 0; i < WROWS; ++i) {
+            int row = trow + 32 * i;
+            *reinterpret_cast<int4v*>(wl + row * BK + ((tchunk ^ (row & 7)) << 3)) = wreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < XROWS; ++i) {
+            int row = trow + 32 * i;
+            *reinterpret_cast<int4v*>(xl + row * BK + ((tchunk ^ (row & 7)) << 3)) = xreg[i];
+        }
+    };
+
+    float4v acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    if (ks < ke) {
+        gload(ks);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int s = ks; s < ke; ++s) {
+        const int buf = (s - ks) & 1;
+        if (s + 1 < ke) gload(s + 1);
+        const half_t* wl = lds + buf * (BN + BM) * BK + (wc * 64) * BK;
+        const half_t* xl = lds + buf * (BN + BM) * BK + BN * BK + (wp * 64) * BK;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 a[4], b[4];
+            const int ch = kk * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row = i * 16 + fr;
+                a[i] = *reinterpret_cast<const half8*>(wl + row * BK + ((ch ^ (row & 7)) << 3));
+                b[i] = *reinterpret_cast<const half8*>(xl + row * BK + ((ch ^ (row & 7)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < ke) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns pixel (pj*16 + fr) and couts (ci*16 + fq*4 .. +3)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wp * 64 + j * 16 + fr;
+        if (m >= p.M) continue;
+        int bsel = 0;
+        if (p.bias_mode == 1) {
+            int r = m % HoWo;
+            int ho = r / p.Wo, wo = r - ho * p.Wo;
+            int rc = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1);
+            int cc = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
+            bsel = (rc * 3 + cc) * p.Cout;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = cout0 + wc * 64 + i * 16 + fq * 4;
+            float4v v = acc[i][j];
+            if (p.partial) {
+                float* dst = p.partial + ((size_t)blockIdx.z * p.M + m) * p.Cout + co;
+                *reinterpret_cast<float4v*>(dst) = v;
+                continue;
+            }
+            if (p.bias) {
+                float4v bv = *reinterpret_cast<const float4v*>(p.bias + bsel + co);
+                v += bv;
+            }
+            if (p.slope) {
+                float4v sv = *reinterpret_cast<const float4v*>(p.slope + co);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * sv[e];
+            }
+            const size_t o = (size_t)m * p.Cout + co;
+            if (p.res) {
+                half4 rv = *reinterpret_cast<const half4*>(p.res + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+            }
+            half4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *reinterpret_cast<half4*>(p.y + o) = hv;
+        }
+    }
+}
+
+template <int WN, bool SMALL>
+static void launch_conv(const ConvP& p, hipStream_t s) {
+    constexpr int BN = 64 * WN, BM = 64 * (4 / WN);
+    dim3 grid((p.M + BM - 1) / BM, p.Cout / BN, p.splitk > 1 ? p.splitk : 1);
+    conv_mfma_kernel<WN, SMALL><<<grid, 256, 0, s>>>(p);
+}
+
+extern "C" int fr_conv_nhwc_f16(const fr_conv_args* a, fr_stream_t stream) {
+    FR_REQUIRE(a, "fr_conv_nhwc_f16: null args");
+    FR_REQUIRE(a->x && a->w && (a->y || a->out_f32_partial), "fr_conv_nhwc_f16: null tensor");
+    FR_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->KH > 0 && a->KW > 0 && a->stride > 0 && a->pad >= 0,
+               "fr_conv_nhwc_f16: bad geometry");
+    FR_REQUIRE(a->Ho == (a->H + 2 * a->pad - a->KH) / a->stride + 1 && a->Wo == (a->W + 2 * a->pad - a->KW) / a->stride + 1,
+               "fr_conv_nhwc_f16: Ho/Wo do not match the geometry");
+    FR_REQUIRE(a->Cout % 64 == 0, "fr_conv_nhwc_f16: Cout must be a multiple of 64 (got %d)", a->Cout);
+    const bool small = a->Cin == 8;
+    FR_REQUIRE(small || a->Cin % 64 == 0, "fr_conv_nhwc_f16: Cin must be 8 or a multiple of 64 (got %d)", a->Cin);
+    FR_REQUIRE(a->bias_mode == 0 || (a->bias_mode == 1 && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 &&
+                                     a->Ho >= 2 && a->Wo >= 2),
+               "fr_conv_nhwc_f16: bias_mode 1 needs a 3x3/s1/p1 conv");
+    FR_REQUIRE(a->H < 32768 && a->W < 32768, "fr_conv_nhwc_f16: H/W too large");
+    ConvP p;
+    p.x = (const half_t*)a->x; p.w = (const half_t*)a->w; p.y = (half_t*)a->y;
+    p.bias = a->bias; p.slope = a->slope; p.res = (const half_t*)a->residual; p.partial = a->out_f32_partial;
+    p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.KH = a->KH; p.KW = a->KW;
+    p.stride = a->stride; p.pad = a->pad; p.Ho = a->Ho; p.Wo = a->Wo; p.bias_mode = a->bias_mode;
+    p.splitk = a->splitk > 1 ? a->splitk : 1;
+    FR_REQUIRE(p.splitk == 1 || p.partial, "fr_conv_nhwc_f16: splitk > 1 needs out_f32_partial");
+    int64_t M = (int64_t)a->B * a->Ho * a->Wo;
+    int64_t xbytes = (int64_t)a->B * a->H * a->W * a->Cin * 2;
+    int Kreal = a->KH * a->KW * a->Cin;
+    p.K = small ? ((Kreal + 127) / 128) * 128 : Kreal;
+    int64_t wbytes = (int64_t)a->Cout * p.K * 2;
+    FR_REQUIRE(M < (1ll << 31) && xbytes < (1ll << 31) && wbytes < (1ll << 31) && M * a->Cout * 2 < (1ll << 40),
+               "fr_conv_nhwc_f16: tensor too large for 32-bit buffer offsets (split the batch)");
+    p.M = (int)M; p.nk = p.K / BK; p.xbytes = (unsigned)xbytes; p.wbytes = (unsigned)wbytes;
+    hipStream_t s = fr_stream(stream);
+    // tile choice: 64-cout layers use 64x256 tiles, the rest 128x128
+    if (small) {
+        if (a->Cout % 128 == 0) launch_conv<2, true>(p, s); else launch_conv<1, true>(p, s);
+    } else if (a->Cout % 128 == 0) {
+        launch_conv<2, false>(p, s);
+    } else {
+        launch_conv<1, false>(p, s);
+    }
+    FR_CHECK_LAUNCH("conv_mfma_kernel");
+    return FR_OK;
+}
+
+// ---- FC tail: reduce split-K partials + bias -> embedding; L2-normalise (one wave per face)
+__global__ void fc_reduce_l2norm(const float* __restrict__ partial, int splitk, int B, int dim,
+                                 const float* __restrict__ bias, float* __restrict__ emb, float* __restrict__ normed) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float ss = 0.f;
+    for (int c = lane * 4; c < dim; c += 256) {
+        float4v v = *reinterpret_cast<const float4v*>(bias + c);
+        for (int z = 0; z < splitk; ++z)
+            v += *reinterpret_cast<const float4v*>(partial + ((size_t)z * B + row) * dim + c);
+        *reinterpret_cast<float4v*>(emb + (size_t)row * dim + c) = v;
+        ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    ss = wave_sum(ss);
+    const float nrm = sqrtf(ss);
+    for (int c = lane * 4; c < dim; c += 256) {
+        float4v v = *reinterpret_cast<const float4v*>(emb + (size_t)row * dim + c);
+        v[0] /= nrm; v[1] /= nrm; v[2] /= nrm; v[3] /= nrm;
+        *reinterpret_cast<float4v*>(normed + (size_t)row * dim + c) = v;
+    }
+}
+
+extern "C" int fr_fc_reduce_l2norm(const float* partial, int splitk, int B, int dim, const float* bias,
+                                   float* embedding, float* normed, fr_stream_t stream) {
+    if (B <= 0) return FR_OK;
+    FR_REQUIRE(partial && bias && embedding && normed, "fr_fc_reduce_l2norm: null pointer");
+    FR_REQUIRE(splitk >= 1 && dim > 0 && dim % 4 == 0, "fr_fc_reduce_l2norm: bad splitk/dim");
+    fc_reduce_l2norm<<<fr_cdiv(B, 4), 256, 0, fr_stream(stream)>>>(partial, splitk, B, dim, bias, embedding, normed);
+    FR_CHECK_LAUNCH("fc_reduce_l2norm");
+    return FR_OK;
+}

@@ -1,0 +1,172 @@
+"""ArcFace IResNet embed network on the HIP conv kernels.
+
+Stands in for the recognition half of ``FaceAnalysis.get`` / ``face.normed_embedding``
+(/root/reference/infrenceServer.py:528,532).  Host side = weight folding + launch plan;
+all arithmetic runs in libfrhip.so (``fr_conv_nhwc_f16``, ``fr_fc_reduce_l2norm``).
+
+Folding (inference BN):  s = gamma / sqrt(var + eps),  t = beta - mean * s.
+  block:  y = bn3(conv2(prelu(bn2(conv1(bn1(x)))))) + shortcut(x)
+  conv1':  w = s2[co] * w1 * s1[ci];  the bn1 shift t1 cannot be a plain bias because the
+           zero padding is applied AFTER bn1, so it becomes a border-class bias
+           bias9[rc][cc][co] = t2[co] + s2[co] * sum_{valid taps} sum_ci w1 * t1[ci]
+           (exact; 9 classes = top/mid/bottom x left/mid/right), epilogue PReLU.
+  conv2':  w = s3[co] * w2, bias t3, epilogue += shortcut (f16 residual stream).
+  shortcut (first block of a stage): 1x1/s2 conv with sd folded, bias td.
+  tail:    bn2 -> flatten(NCHW) -> fc -> features(BN1d) folds into one 25088->512 GEMM
+           (columns permuted to NHWC order), run split-K on the same MFMA kernel.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .weights import IRESNET_LAYERS, IRESNET_WIDTHS
+
+BN_EPS = 1e-5
+FC_SPLITK = 28
+
+
+def _bn_fold(st, prefix):
+    s = st[prefix + ".weight"].double() / torch.sqrt(st[prefix + ".running_var"].double() + BN_EPS)
+    t = st[prefix + ".bias"].double() - st[prefix + ".running_mean"].double() * s
+    return s, t
+
+
+def _pack_w(w):
+    """[Cout,Cin,KH,KW] -> [Cout, KH*KW*Cin] f16 (K contiguous, tap-major)."""
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(torch.float16).contiguous()
+
+
+class _Conv:
+    __slots__ = ("w", "bias", "slope", "cin", "cout", "k", "stride", "pad", "bias_mode")
+
+    def __init__(self, w, bias, slope, cin, cout, k, stride, pad, bias_mode, device):
+        self.w = w.to(device)
+        self.bias = None if bias is None else bias.to(torch.float32).contiguous().to(device)
+        self.slope = None if slope is None else slope.to(torch.float32).contiguous().to(device)
+        self.cin, self.cout, self.k, self.stride, self.pad, self.bias_mode = cin, cout, k, stride, pad, bias_mode
+
+
+class IResNetHIP:
+    """Folded IResNet resident on one GPU.  ``forward`` takes the packed stem input
+    f16 [B,112,112,8] (RGB in channels 0..2, (x-127.5)/127.5, rest zero) produced by
+    ``fr_warp_affine_5pt`` and returns (embedding, normed_embedding) f32 [B,512] on device."""
+
+    def __init__(self, state, arch="r100", device="cuda:0", max_chunk=256):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.arch = arch
+        self.max_chunk = max_chunk
+        layers = IRESNET_LAYERS[arch]
+        st = {k: v.detach().to("cpu") for k, v in state.items()}
+        dev = self.device
+        # stem: conv1 + bn1 + prelu, packed K = 16 taps x 8 channels
+        s, t = _bn_fold(st, "bn1")
+        w = st["conv1.weight"].double() * s[:, None, None, None]
+        wp = torch.zeros(64, 16, 8, dtype=torch.float64)
+        wp[:, :9, :3] = w.permute(0, 2, 3, 1).reshape(64, 9, 3)
+        self.stem = _Conv(wp.reshape(64, 128).to(torch.float16).contiguous(), t, st["prelu.weight"], 8, 64, 3, 1, 1, 0, dev)
+        self.blocks = []
+        cin = 64
+        for li, (n, cout) in enumerate(zip(layers, IRESNET_WIDTHS), start=1):
+            for bi in range(n):
+                p = f"layer{li}.{bi}"
+                stride = 2 if bi == 0 else 1
+                s1, t1 = _bn_fold(st, p + ".bn1")
+                s2, t2 = _bn_fold(st, p + ".bn2")
+                s3, t3 = _bn_fold(st, p + ".bn3")
+                w1 = st[p + ".conv1.weight"].double()
+                w1f = w1 * s2[:, None, None, None] * s1[None, :, None, None]
+                tap = (w1 * t1[None, :, None, None]).sum(1) * s2[:, None, None]      # [co,kh,kw]
+                valid = {0: [1, 2], 1: [0, 1, 2], 2: [0, 1]}
+                bias9 = torch.empty(3, 3, cout, dtype=torch.float64)
+                for rc in range(3):
+                    for cc in range(3):
+                        bias9[rc, cc] = t2 + tap[:, valid[rc]][:, :, valid[cc]].sum((1, 2))
+                c1 = _Conv(_pack_w(w1f), bias9.reshape(9 * cout), st[p + ".prelu.weight"], cin, cout, 3, 1, 1, 1, dev)
+                w2f = st[p + ".conv2.weight"].double() * s3[:, None, None, None]
+                c2 = _Conv(_pack_w(w2f), t3, None, cout, cout, 3, stride, 1, 0, dev)
+                sc = None
+                if bi == 0:
+                    sd, td = _bn_fold(st, p + ".downsample.1")
+                    wd = st[p + ".downsample.0.weight"].double() * sd[:, None, None, None]
+                    sc = _Conv(_pack_w(wd), td, None, cin, cout, 1, stride, 0, 0, dev)
+                self.blocks.append((c1, c2, sc))
+                cin = cout
+        # tail
+        sb, tb = _bn_fold(st, "bn2")
+        sf, tf = _bn_fold(st, "features")
+        W = st["fc.weight"].double().reshape(512, 512, 49)                   # [o, c, hw]
+        bias = sf * (st["fc.bias"].double() + (W * tb[None, :, None]).sum((1, 2))) + tf
+        Wf = (W * sb[None, :, None] * sf[:, None, None]).permute(0, 2, 1).reshape(512, 49 * 512)   # NHWC K order
+        self.fc_w = Wf.to(torch.float16).contiguous().to(dev)
+        self.fc_bias = bias.to(torch.float32).contiguous().to(dev)
+        self.flops_per_face = self._count_flops()
+
+    def _count_flops(self):
+        f, hw = 2 * 112 * 112 * 27 * 64, 112
+        for c1, c2, sc in self.blocks:
+            f += 2 * hw * hw * c1.cin * c1.cout * 9
+            ho = hw // c2.stride
+            f += 2 * ho * ho * c2.cin * c2.cout * 9
+            if sc is not None:
+                f += 2 * ho * ho * sc.cin * sc.cout
+            hw = ho
+        return f + 2 * 25088 * 512
+
+    # ---- launches
+    def _conv(self, x, c, B, H, W, residual=None, partial=None, splitk=1, y=None):
+        Ho = (H + 2 * c.pad - c.k) // c.stride + 1
+        Wo = (W + 2 * c.pad - c.k) // c.stride + 1
+        if partial is None and y is None:
+            y = torch.empty((B, Ho, Wo, c.cout), dtype=torch.float16, device=self.device)
+        a = _lib.ConvArgs(_lib.ptr(x), _lib.ptr(c.w) if isinstance(c, _Conv) else None, _lib.ptr(y),
+                          _lib.ptr(c.bias), _lib.ptr(c.slope), _lib.ptr(residual), _lib.ptr(partial),
+                          B, H, W, c.cin, c.cout, c.k, c.k, c.stride, c.pad, Ho, Wo, c.bias_mode, splitk)
+        self.lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
+        return y, Ho, Wo
+
+    def forward(self, x, taps=None):
+        assert x.dtype == torch.float16 and x.shape[1:] == (112, 112, 8) and x.is_contiguous()
+        B = x.shape[0]
+        emb = torch.empty((B, 512), dtype=torch.float32, device=self.device)
+        normed = torch.empty_like(emb)
+        with torch.cuda.device(self.device):
+            for b0 in range(0, B, self.max_chunk):
+                b1 = min(B, b0 + self.max_chunk)
+                self._forward_chunk(x[b0:b1], emb[b0:b1], normed[b0:b1], taps)
+        return emb, normed
+
+    def _forward_chunk(self, x, emb, normed, taps):
+        B = x.shape[0]
+        h, H, W = self._conv(x, self.stem, B, 112, 112)
+        if taps is not None:
+            taps["stem"] = h
+        li = 0
+        for c1, c2, sc in self.blocks:
+            mid, _, _ = self._conv(h, c1, B, H, W)
+            if sc is not None:
+                li += 1
+                if taps is not None:
+                    taps[f"layer{li}.0.mid"] = mid
+                short, _, _ = self._conv(h, sc, B, H, W)
+            else:
+                short = h
+            h, H, W = self._conv(mid, c2, B, H, W, residual=short)
+            if taps is not None:
+                taps[f"_block{len(taps)}"] = None
+        if taps is not None:
+            taps["final"] = h
+        # FC as a 1x1 conv over a 1x1 image with Cin = 25088, split-K -> f32 partials
+        partial = torch.empty((FC_SPLITK, B, 512), dtype=torch.float32, device=self.device)
+        fc = _FC(self.fc_w)
+        self._conv(h, fc, B, 1, 1, partial=partial, splitk=FC_SPLITK)
+        self.lib.fr_fc_reduce_l2norm(_lib.ptr(partial), FC_SPLITK, B, 512, _lib.ptr(self.fc_bias),
+                                     _lib.ptr(emb), _lib.ptr(normed), _lib.stream_ptr())
+
+
+class _FC(_Conv):
+    def __init__(self, w):
+        self.w, self.bias, self.slope = w, None, None
+        self.cin, self.cout, self.k, self.stride, self.pad, self.bias_mode = 25088, 512, 1, 1, 0, 0

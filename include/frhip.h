@@ -56,6 +56,33 @@ int fr_f32_to_f16(const float* x, void* out, int64_t n, fr_stream_t stream);
 int fr_match_decide(const int64_t* idx, const float* score, int F, float thr, float unknown_thr,
                     int32_t* decision, fr_stream_t stream);
 
+
+/* ---------------------------------------------------------------- embed ----
+ * a-4  ArcFace IResNet conv stack (inside FaceAnalysis.get, infrenceServer.py:528).
+ * Implicit-GEMM convolution on MFMA, NHWC f16 activations, f32 accumulate:
+ *   y[n,ho,wo,co] = epi( sum_{kh,kw,ci} x[n,ho*s+kh-p,wo*s+kw-p,ci] * w[co,kh,kw,ci] )
+ *   epi(v) = prelu(v + bias) (+ residual)
+ * w: [Cout][KH*KW*Cin] f16 (K contiguous).  Cin % 64 == 0, or Cin == 8 (packed stem: w rows
+ * zero-padded to a multiple of 128).  Cout % 64 == 0.
+ * bias: f32 [Cout] (bias_mode 0) or [9][Cout] (bias_mode 1: border-class bias
+ * [row class: top/mid/bottom][col class: left/mid/right] that carries a folded
+ * pre-activation BN shift through the zero padding; 3x3/s1/p1 only), or NULL.
+ * slope: f32 [Cout] PReLU slopes or NULL.  residual: f16 [M,Cout] or NULL.
+ * out_f32_partial != NULL: split-K mode, raw f32 partial sums [splitk][M][Cout]
+ * (no epilogue), used for the FC 25088->512 (H=W=1, Cin=25088). */
+typedef struct {
+    const void* x; const void* w; void* y;
+    const float* bias; const float* slope; const void* residual;
+    float* out_f32_partial;
+    int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+    int bias_mode; int splitk;
+} fr_conv_args;
+int fr_conv_nhwc_f16(const fr_conv_args* args, fr_stream_t stream);
+/* FC tail: sum split-K partials + bias -> embedding f32 [B,dim]; then
+ * normed_embedding = embedding / ||embedding|| (Face.normed_embedding, infrenceServer.py:532) */
+int fr_fc_reduce_l2norm(const float* partial, int splitk, int B, int dim, const float* bias,
+                        float* embedding, float* normed, fr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

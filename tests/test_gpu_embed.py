@@ -1,0 +1,123 @@
+"""GPU parity: IResNet conv stack through the C ABI vs the torch-CPU fp32 oracle.
+Tolerance (north_star): embeddings within 1e-3 cosine of the CPU path."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def nchw_to_nhwc8(x):
+    """float32 [B,3,H,W] -> f16 [B,H,W,8] (channels 0..2, rest zero)."""
+    B, C, H, W = x.shape
+    out = torch.zeros((B, H, W, 8), dtype=torch.float16)
+    out[..., :C] = x.permute(0, 2, 3, 1).to(torch.float16)
+    return out.cuda()
+
+
+def _conv_case(lib, B, H, W, Cin, Cout, k, stride, pad, bias_mode, slope, residual, seed):
+    from facerecognition_infrenceengine_amd import _lib
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((B, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, k, k), generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    xh = x.to(torch.float16); wh = w.to(torch.float16)
+    ref = F.conv2d(xh.float(), wh.float(), None, stride, pad)          # f16-rounded inputs, f32 math
+    bias = None
+    if bias_mode == 1:
+        b9 = torch.randn((3, 3, Cout), generator=g)
+        rc = torch.ones(Ho, dtype=torch.long); rc[0] = 0; rc[-1] = 2
+        cc = torch.ones(Wo, dtype=torch.long); cc[0] = 0; cc[-1] = 2
+        ref = ref + b9[rc][:, cc].permute(2, 0, 1)[None]
+        bias = b9.reshape(-1)
+    else:
+        bias = torch.randn(Cout, generator=g)
+        ref = ref + bias[None, :, None, None]
+    sl = None
+    if slope:
+        sl = torch.rand(Cout, generator=g) * 0.5
+        ref = torch.where(ref > 0, ref, ref * sl[None, :, None, None])
+    res = None
+    if residual:
+        res = torch.randn((B, Ho, Wo, Cout), generator=g).to(torch.float16)
+        ref = ref + res.float().permute(0, 3, 1, 2)
+    xd = xh.permute(0, 2, 3, 1).contiguous().cuda()
+    wd = wh.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().cuda()
+    y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float16, device="cuda")
+    bd = bias.cuda(); sd = sl.cuda() if sl is not None else None; rd = res.cuda() if res is not None else None
+    a = _lib.ConvArgs(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), _lib.ptr(bd), _lib.ptr(sd), _lib.ptr(rd), None,
+                      B, H, W, Cin, Cout, k, k, stride, pad, Ho, Wo, bias_mode, 1)
+    lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 2e-3 * scale + 2e-3, (err, scale)
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, k, stride, pad, bias_mode, slope, residual
+    (2, 14, 14, 256, 256, 3, 1, 1, 1, True, False),      # stage-3 conv1 (border-class bias + PReLU)
+    (2, 14, 14, 256, 256, 3, 1, 1, 0, False, True),      # stage-3 conv2 (+ residual)
+    (3, 28, 28, 128, 256, 3, 1, 1, 1, True, False),      # M tail: 3*784 = 2352 (not a tile multiple)
+    (2, 28, 28, 256, 256, 3, 2, 1, 0, False, True),      # stride-2 conv2
+    (2, 56, 56, 64, 128, 1, 2, 0, 0, False, False),      # 1x1/s2 shortcut
+    (1, 56, 56, 64, 64, 3, 1, 1, 1, True, False),        # 64-cout tile shape
+    (5, 7, 7, 512, 512, 3, 1, 1, 0, False, True),        # 7x7 stage, ragged M = 245
+    (1, 9, 5, 64, 64, 3, 1, 1, 1, True, True),           # tiny odd image
+])
+def test_conv_layer_vs_torch(lib, case):
+    _conv_case(lib, *case, seed=hash(case) & 0xffff)
+
+
+def test_mfma_layout_integer_exact(lib):
+    """A = small integers, asymmetric: catches a transposed / permuted fragment map exactly."""
+    from facerecognition_infrenceengine_amd import _lib
+    Cin, Cout, B, H, W = 64, 64, 1, 4, 16                  # 1x1 conv == plain GEMM [64 px] x [64 -> 64]
+    x = (torch.arange(B * H * W * Cin).reshape(B, H, W, Cin) % 7 - 3).to(torch.float16)
+    w = ((torch.arange(Cout * Cin).reshape(Cout, Cin) * 5) % 11 - 5).to(torch.float16)
+    ref = x.reshape(-1, Cin).float() @ w.float().T
+    y = torch.empty((B, H, W, Cout), dtype=torch.float16, device="cuda")
+    xd, wd = x.cuda(), w.cuda()
+    a = _lib.ConvArgs(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), None, None, None, None,
+                      B, H, W, Cin, Cout, 1, 1, 1, 0, H, W, 0, 1)
+    lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
+    assert torch.equal(y.float().cpu().reshape(-1, Cout), ref)
+
+
+@pytest.fixture(scope="module")
+def r100():
+    from facerecognition_infrenceengine_amd import weights
+    from facerecognition_infrenceengine_amd.iresnet import IResNetHIP
+    return IResNetHIP(weights.synth_iresnet_state("r100", seed=1234), "r100", "cuda:0")
+
+
+def test_r100_embedding_vs_golden(r100, golden):
+    d = golden("r100_kat.npz")
+    x = torch.from_numpy(d["x"])
+    taps = {}
+    emb, normed = r100.forward(nchw_to_nhwc8(x), taps)
+    emb = emb.cpu().numpy(); normed = normed.cpu().numpy()
+    ref = d["embedding"]
+    cos = (emb * ref).sum(1) / (np.linalg.norm(emb, axis=1) * np.linalg.norm(ref, axis=1))
+    assert (1 - cos).max() < 1e-3, cos                     # north_star tolerance
+    np.testing.assert_allclose(np.linalg.norm(normed, axis=1), 1.0, atol=1e-6)
+    np.testing.assert_allclose(normed, emb / np.linalg.norm(emb, axis=1, keepdims=True), atol=1e-6)
+    # layer taps (oracle NCHW, subsampled [:, ::8, ::3, ::3])
+    for name in ("stem", "layer1.0.mid", "layer3.0.mid"):
+        got = taps[name].float().cpu().permute(0, 3, 1, 2)[:, ::8, ::3, ::3].numpy()
+        want = d["tap_" + name.replace(".", "_")]
+        assert np.abs(got - want).max() <= 0.02 * np.abs(want).max(), name
+
+
+def test_r100_batch_independence(r100):
+    """Size-independent property at a ragged batch: rows do not depend on their batch mates."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand((5, 3, 112, 112), generator=g) * 2 - 1
+    xa = nchw_to_nhwc8(x)
+    e_all, _ = r100.forward(xa)
+    e_one, _ = r100.forward(xa[3:4].contiguous())
+    assert torch.equal(e_all[3:4], e_one)
