@@ -38,6 +38,15 @@ SIGNATURES = {
     "fr_match_decide": (_I, [_P, _P, _I, _F, _F, _P, _P]),
     "fr_conv_nhwc_f16": (_I, [C.POINTER(ConvArgs), _P]),
     "fr_fc_reduce_l2norm": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
+    "fr_warp_affine_5pt": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "fr_pyramid_resize_norm": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "fr_dconv_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "fr_maxpool_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fr_pnet_candidates": (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "fr_sort_nms": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P, _P, _I, _P]),
+    "fr_box_refine": (_I, [_P, _P, _I, _P, _I, _I, _I, _P]),
+    "fr_crop_resize_norm": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
+    "fr_stage_select": (_I, [_P, _P, _I, _P, _I, _I, _F, _P, _P, _P, _I, _P, _P, _P]),
 }
 
 _NOCHECK = ("fr_version", "fr_device_count")

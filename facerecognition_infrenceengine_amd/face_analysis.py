@@ -1,0 +1,146 @@
+"""``FaceAnalysis``-shaped engine: the drop-in for the object the reference builds at
+/root/reference/infrenceServer.py:412-416 (``FaceAnalysis(name=..., providers=...)``,
+``.prepare(ctx_id=0)``) and calls at :528 (``.get(frame) -> [Face]``).
+
+The reference reads three Face fields only: ``bbox`` (:531), ``normed_embedding`` (:532) and
+``det_score`` (:557); ``kps`` and ``embedding`` are provided as insightface does.
+
+detect (MTCNN, HIP) -> align (5-point warp, HIP) -> embed (IResNet on MFMA, HIP); the match
+step lives in ``gallery.GalleryMatcher``.  There is no CPU path: construction succeeds
+anywhere, ``prepare`` raises without a HIP device.
+"""
+import os
+import threading
+import warnings
+
+import numpy as np
+import torch
+
+from . import _lib, weights
+
+
+class Face(dict):
+    """Attribute-style record like insightface's Face (``face.bbox`` and ``face['bbox']``)."""
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        self[name] = value
+
+
+def _model_dir(name, root):
+    return os.path.join(os.path.expanduser(root), "models", name)
+
+
+class FaceAnalysis:
+    """Same constructor / prepare / get surface as insightface.app.FaceAnalysis.
+
+    ``name`` selects a model directory ``<root>/models/<name>/`` holding ``arcface_<arch>.pt|.safetensors``
+    and ``mtcnn_{pnet,rnet,onet}.pt`` state dicts (public PyTorch naming, see weights.py).  When the
+    directory is absent the engine falls back to SEEDED SYNTHETIC weights and says so loudly:
+    the pipeline is then numerically exact w.r.t. its oracle but recognises nothing.
+    ``providers`` is accepted for signature compatibility and ignored (HIP only).
+    """
+
+    def __init__(self, name="buffalo_l", root="~/.insightface", allowed_modules=None, providers=None,
+                 arch="r100", **kwargs):
+        self.name, self.root, self.providers, self.arch = name, root, providers, arch
+        self.det = self.rec = None
+        self._lock = threading.Lock()         # one engine may be shared by threads (trainingServer.py:115,227)
+        self.det_kwargs = {k: kwargs[k] for k in ("minsize", "factor", "thresholds", "cap_scale", "keep_scale",
+                                                  "cap_p", "cap_r", "cap_o") if k in kwargs}
+        self.synthetic = None
+
+    def _load_states(self):
+        d = _model_dir(self.name, self.root)
+        rec = det = None
+        for ext in (".safetensors", ".pt", ".pth"):
+            p = os.path.join(d, f"arcface_{self.arch}{ext}")
+            if rec is None and os.path.exists(p):
+                rec = weights.load_state(p)
+            ps = [os.path.join(d, f"mtcnn_{n}{ext}") for n in ("pnet", "rnet", "onet")]
+            if det is None and all(os.path.exists(q) for q in ps):
+                det = tuple(weights.load_state(q) for q in ps)
+        self.synthetic = rec is None or det is None
+        if self.synthetic:
+            warnings.warn(f"model pack '{self.name}' not found under {d}: using SEEDED SYNTHETIC weights "
+                          f"(numerically exact pipeline, meaningless identities)")
+        return (rec or weights.synth_iresnet_state(self.arch), det or weights.synth_mtcnn_states())
+
+    def prepare(self, ctx_id=0, det_thresh=None, det_size=None):
+        """``ctx_id`` = HIP device ordinal (infrenceServer.py:416).  ``det_size`` is accepted and
+        ignored (MTCNN runs the full pyramid of the frame)."""
+        from .iresnet import IResNetHIP
+        from .mtcnn import MTCNNHIP
+        _lib.require_gpu()
+        self.device = torch.device(f"cuda:{max(int(ctx_id), 0)}")
+        rec, det = self._load_states()
+        self.rec = IResNetHIP(rec, self.arch, self.device)
+        self.det = MTCNNHIP(*det, device=self.device, **self.det_kwargs)
+        self.lib = _lib.load()
+        return self
+
+    # ------------------------------------------------------------------ device-side pipeline
+    def detect_embed_device(self, frames):
+        """frames: uint8 [N,H,W,3] BGR on the device.  One host sync (face counts).
+
+        Returns dict of device tensors for the F detected faces (frame-major, descending score
+        within a frame): frame_idx i32 [F], bbox f32 [F,4], kps f32 [F,5,2], det_score f32 [F],
+        embedding f32 [F,512], normed_embedding f32 [F,512]; plus counts (host list)."""
+        if self.det is None:
+            raise _lib.FrError("FaceAnalysis.prepare() has not been called")
+        N, H, W, _ = frames.shape
+        boxes, scores, kps, counts = self.det.detect_batch(frames)
+        cap = boxes.shape[1]
+        cnt = counts.cpu()                                            # the one sync of the pipeline
+        mask = torch.arange(cap)[None, :] < cnt[:, None]
+        sel = mask.reshape(-1).nonzero().squeeze(1).to(self.device)   # frame-major valid slots
+        F = sel.numel()
+        frame_idx = (sel // cap).to(torch.int32)
+        out = {"counts": cnt.tolist(), "frame_idx": frame_idx,
+               "bbox": boxes.reshape(-1, 4)[sel], "kps": kps.reshape(-1, 5, 2)[sel].contiguous(),
+               "det_score": scores.reshape(-1)[sel]}
+        emb = torch.empty((F, 512), dtype=torch.float32, device=self.device)
+        normed = torch.empty_like(emb)
+        if F:
+            with torch.cuda.device(self.device):
+                crops = torch.empty((F, 112, 112, 8), dtype=torch.float16, device=self.device)
+                self.lib.fr_warp_affine_5pt(_lib.ptr(frames), N, H, W, _lib.ptr(out["kps"]), _lib.ptr(frame_idx), None,
+                                            F, 112, _lib.ptr(crops), None, None, _lib.stream_ptr())
+                emb, normed = self.rec.forward(crops)
+        out["embedding"], out["normed_embedding"] = emb, normed
+        return out
+
+    # ------------------------------------------------------------------ reference-shaped API
+    def get_batch(self, frames):
+        """list/array of same-sized BGR uint8 frames -> list (per frame) of lists of Face."""
+        arr = np.ascontiguousarray(np.stack([np.asarray(f) for f in frames]) if not isinstance(frames, np.ndarray)
+                                   else frames)
+        if arr.ndim != 4 or arr.shape[3] != 3 or arr.dtype != np.uint8:
+            raise ValueError("frames must be uint8 [N,H,W,3] BGR")
+        with self._lock:
+            dev = torch.from_numpy(arr).to(self.device)
+            r = self.detect_embed_device(dev)
+            host = {k: r[k].cpu().numpy() for k in ("bbox", "kps", "det_score", "embedding", "normed_embedding")}
+        res, i = [], 0
+        for n in r["counts"]:
+            faces = []
+            for _ in range(n):
+                faces.append(Face(bbox=host["bbox"][i].copy(), kps=host["kps"][i].copy(),
+                                  det_score=float(host["det_score"][i]), embedding=host["embedding"][i].copy(),
+                                  normed_embedding=host["normed_embedding"][i].copy()))
+                i += 1
+            res.append(faces)
+        return res
+
+    def get(self, img, max_num=0):
+        """One BGR uint8 HWC frame -> list of Face (descending det_score), as infrenceServer.py:528."""
+        faces = self.get_batch(np.asarray(img)[None])[0]
+        return faces[:max_num] if max_num else faces
+
+
+FaceEngine = FaceAnalysis

@@ -1,0 +1,230 @@
+"""MTCNN cascade on the HIP detector kernels.
+
+Detector half of ``FaceAnalysis.get`` (/root/reference/infrenceServer.py:528).  The host side is
+a launch plan only: every stage works on fixed-capacity per-frame slot lists with device-side
+counts, so a whole batch of frames runs without a host synchronisation.  Conventions (resize,
+ordering, thresholds, capacities) are those written down in ``oracle/detect.py``.
+"""
+import math
+
+import torch
+
+from . import _lib
+
+
+def pyramid_scales(h, w, minsize=20, factor=0.709):
+    m = 12.0 / minsize
+    minl = min(h, w) * m
+    scales, k = [], 0
+    while minl >= 12:
+        scales.append(m * factor ** k)
+        minl *= factor
+        k += 1
+    return scales
+
+
+def _pool_out(n, k, s):
+    o = -(-(n - k) // s) + 1
+    if (o - 1) * s >= n:
+        o -= 1
+    return o
+
+
+class _DConv:
+    """Direct-conv layer: weights [KH][KW][Cin][CoutP] f32, bias/slope [CoutP]."""
+
+    def __init__(self, w, b, slope, device, pool2=False, head=None):
+        cout, cin, kh, kw = w.shape
+        gran = 32 if cout % 32 == 0 else 16
+        coutp = -(-cout // gran) * gran
+        wp = torch.zeros((kh, kw, cin, coutp), dtype=torch.float32)
+        wp[..., :cout] = w.permute(2, 3, 1, 0)
+        bp = torch.zeros(coutp); bp[:cout] = b
+        self.w = wp.contiguous().to(device)
+        self.b = bp.to(device)
+        self.slope = None
+        if slope is not None:
+            sp = torch.zeros(coutp); sp[:cout] = slope
+            self.slope = sp.to(device)
+        self.cin, self.cout, self.coutp, self.kh, self.kw, self.pool2 = cin, cout, coutp, kh, kw, pool2
+        self.head_w = self.head_b = None
+        self.nhead = 0
+        if head is not None:                       # (w [nh, cout], b [nh])
+            self.head_w = head[0].t().contiguous().to(torch.float32).to(device)      # [cout][nh]
+            self.head_b = head[1].to(torch.float32).contiguous().to(device)
+            self.nhead = head[0].shape[0]
+
+    def out_hw(self, h, w):
+        hc, wc = h - self.kh + 1, w - self.kw + 1
+        return ((hc + 1) // 2, (wc + 1) // 2) if self.pool2 else (hc, wc)
+
+
+def _dense_as_conv(w, k, c):
+    """MTCNN dense layer over a k x k x c map flattened (w, h, c) -> conv weight [o, c, kh, kw]."""
+    o = w.shape[0]
+    return w.reshape(o, k, k, c).permute(0, 3, 2, 1).contiguous()      # [o, w, h, c] -> [o, c, h, w]
+
+
+class MTCNNHIP:
+    def __init__(self, pstate, rstate, ostate, device="cuda:0", minsize=20, factor=0.709,
+                 thresholds=(0.6, 0.7, 0.7), cap_scale=2048, keep_scale=256, cap_p=512, cap_r=64, cap_o=16):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.minsize, self.factor, self.thresholds = minsize, factor, tuple(float(t) for t in thresholds)
+        self.cap_scale, self.keep_scale, self.cap_p, self.cap_r, self.cap_o = cap_scale, keep_scale, cap_p, cap_r, cap_o
+        assert cap_scale <= 4096 and cap_p <= 1024 and cap_r <= 1024 and cap_o <= 1024
+        d = self.device
+        p, r, o = ({k: v.detach().float().cpu() for k, v in s.items()} for s in (pstate, rstate, ostate))
+        self.p1 = _DConv(p["conv1.weight"], p["conv1.bias"], p["prelu1.weight"], d, pool2=True)
+        self.p2 = _DConv(p["conv2.weight"], p["conv2.bias"], p["prelu2.weight"], d)
+        hw = torch.cat([p["conv4_1.weight"].reshape(2, 32), p["conv4_2.weight"].reshape(4, 32)])
+        hb = torch.cat([p["conv4_1.bias"], p["conv4_2.bias"]])
+        self.p3 = _DConv(p["conv3.weight"], p["conv3.bias"], p["prelu3.weight"], d, head=(hw, hb))
+        self.r1 = _DConv(r["conv1.weight"], r["conv1.bias"], r["prelu1.weight"], d)
+        self.r2 = _DConv(r["conv2.weight"], r["conv2.bias"], r["prelu2.weight"], d)
+        self.r3 = _DConv(r["conv3.weight"], r["conv3.bias"], r["prelu3.weight"], d)
+        self.r4 = _DConv(_dense_as_conv(r["dense4.weight"], 3, 64), r["dense4.bias"], r["prelu4.weight"], d)
+        self.r5 = _DConv(torch.cat([r["dense5_1.weight"], r["dense5_2.weight"]]).reshape(6, 128, 1, 1),
+                         torch.cat([r["dense5_1.bias"], r["dense5_2.bias"]]), None, d)
+        self.o1 = _DConv(o["conv1.weight"], o["conv1.bias"], o["prelu1.weight"], d)
+        self.o2 = _DConv(o["conv2.weight"], o["conv2.bias"], o["prelu2.weight"], d)
+        self.o3 = _DConv(o["conv3.weight"], o["conv3.bias"], o["prelu3.weight"], d)
+        self.o4 = _DConv(o["conv4.weight"], o["conv4.bias"], o["prelu4.weight"], d)
+        self.o5 = _DConv(_dense_as_conv(o["dense5.weight"], 3, 128), o["dense5.bias"], o["prelu5.weight"], d)
+        self.o6 = _DConv(torch.cat([o["dense6_1.weight"], o["dense6_2.weight"], o["dense6_3.weight"]]).reshape(16, 256, 1, 1),
+                         torch.cat([o["dense6_1.bias"], o["dense6_2.bias"], o["dense6_3.bias"]]), None, d)
+
+    # ---- thin launch helpers (all on the current stream)
+    def _f32(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    def _i32(self, *shape):
+        return torch.empty(shape, dtype=torch.int32, device=self.device)
+
+    def _dconv(self, x, c, B, H, W):
+        ho, wo = c.out_hw(H, W)
+        y = self._f32(B, ho, wo, c.nhead if c.nhead else c.cout)
+        self.lib.fr_dconv_f32(_lib.ptr(x), _lib.ptr(c.w), _lib.ptr(c.b), _lib.ptr(c.slope), _lib.ptr(y), B, H, W,
+                              c.cin, c.cout, c.coutp, c.kh, c.kw, 1 if c.pool2 else 0, _lib.ptr(c.head_w),
+                              _lib.ptr(c.head_b), c.nhead, self._s)
+        return y, ho, wo
+
+    def _pool(self, x, B, H, W, C, k, s):
+        ho, wo = _pool_out(H, k, s), _pool_out(W, k, s)
+        y = self._f32(B, ho, wo, C)
+        self.lib.fr_maxpool_f32(_lib.ptr(x), _lib.ptr(y), B, H, W, C, k, s, self._s)
+        return y, ho, wo
+
+    def _nms(self, boxes, scores, aux, naux, counts, L, nseg, seg_cap, seg_major, thr, mode, keep):
+        bo, so, co = self._f32(L, keep, 4), self._f32(L, keep), self._i32(L)
+        ao = self._f32(L, keep, max(naux, 1))
+        self.lib.fr_sort_nms(_lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(aux), naux, _lib.ptr(counts), L, nseg, seg_cap,
+                             seg_major, thr, mode, keep, _lib.ptr(bo), _lib.ptr(so), _lib.ptr(ao), _lib.ptr(co), keep,
+                             self._s)
+        return bo, so, ao, co
+
+    # ---- nets
+    def pnet_level(self, frames, scale, trace=None):
+        """frames u8 [N,H,W,3] -> head f32 [N,hc,wc,6] of one pyramid level."""
+        N, H, W, _ = frames.shape
+        hs, ws = int(math.ceil(H * scale)), int(math.ceil(W * scale))
+        img = self._f32(N, hs, ws, 3)
+        self.lib.fr_pyramid_resize_norm(_lib.ptr(frames), N, H, W, hs, ws, _lib.ptr(img), self._s)
+        x, h, w = self._dconv(img, self.p1, N, hs, ws)
+        x, h, w = self._dconv(x, self.p2, N, h, w)
+        head, h, w = self._dconv(x, self.p3, N, h, w)
+        if trace is not None:
+            trace.setdefault("pnet_img", []).append(img)
+        return head, h, w
+
+    def rnet(self, x, B):
+        x, h, w = self._dconv(x, self.r1, B, 24, 24)
+        x, h, w = self._pool(x, B, h, w, 28, 3, 2)
+        x, h, w = self._dconv(x, self.r2, B, h, w)
+        x, h, w = self._pool(x, B, h, w, 48, 3, 2)
+        x, h, w = self._dconv(x, self.r3, B, h, w)
+        x, h, w = self._dconv(x, self.r4, B, h, w)
+        x, h, w = self._dconv(x, self.r5, B, 1, 1)
+        return x.reshape(B, 6)
+
+    def onet(self, x, B):
+        x, h, w = self._dconv(x, self.o1, B, 48, 48)
+        x, h, w = self._pool(x, B, h, w, 32, 3, 2)
+        x, h, w = self._dconv(x, self.o2, B, h, w)
+        x, h, w = self._pool(x, B, h, w, 64, 3, 2)
+        x, h, w = self._dconv(x, self.o3, B, h, w)
+        x, h, w = self._pool(x, B, h, w, 64, 2, 2)
+        x, h, w = self._dconv(x, self.o4, B, h, w)
+        x, h, w = self._dconv(x, self.o5, B, h, w)
+        x, h, w = self._dconv(x, self.o6, B, 1, 1)
+        return x.reshape(B, 16)
+
+    # ---- cascade
+    def detect_batch(self, frames, trace=None):
+        """frames: uint8 [N,H,W,3] BGR device tensor (contiguous).
+
+        Returns device tensors: boxes f32 [N,cap_o,4], scores f32 [N,cap_o], kps f32 [N,cap_o,5,2],
+        counts i32 [N] (faces per frame, in descending-score order)."""
+        assert frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[3] == 3 and frames.is_contiguous()
+        N, H, W, _ = frames.shape
+        lib, t0, t1, t2 = self.lib, *self.thresholds
+        with torch.cuda.device(self.device):
+            self._s = _lib.stream_ptr()
+            scales = pyramid_scales(H, W, self.minsize, self.factor)
+            nlev = len(scales)
+            if nlev == 0:                       # frame smaller than one 12-px cell at the coarsest usable scale
+                z = torch.zeros((N, self.cap_o, 14), dtype=torch.float32, device=self.device)
+                return (z[..., :4].contiguous(), z[..., 0].contiguous(), z[..., 4:14].unflatten(-1, (5, 2)),
+                        torch.zeros(N, dtype=torch.int32, device=self.device))
+            assert nlev * self.keep_scale <= 4096, "too many pyramid levels for the merged NMS list"
+            cs = self.cap_scale
+            lb, ls, lr, lc = self._f32(nlev, N, cs, 4), self._f32(nlev, N, cs), self._f32(nlev, N, cs, 4), self._i32(nlev, N)
+            for li, s in enumerate(scales):
+                head, hc, wc = self.pnet_level(frames, s, trace)
+                nblk = -(-hc * wc // 256)
+                bc = self._i32(N * nblk)
+                prob = self._f32(N, hc, wc) if trace is not None else None
+                lib.fr_pnet_candidates(_lib.ptr(head), N, hc, wc, float(s), t0, cs, _lib.ptr(lb[li]), _lib.ptr(ls[li]),
+                                       _lib.ptr(lr[li]), _lib.ptr(lc[li]), _lib.ptr(bc), _lib.ptr(prob), self._s)
+                if trace is not None:
+                    trace.setdefault("pnet_head", []).append(head)
+                    trace.setdefault("pnet_prob", []).append(prob)
+            # per-level NMS 0.5 -> keep_scale survivors; then cross-level NMS 0.7 -> cap_p
+            kb, ks, ka, kc = self._nms(lb, ls, lr, 4, lc, nlev * N, 1, cs, 0, 0.5, 0, self.keep_scale)
+            b1, s1, a1, c1 = self._nms(kb, ks, ka, 4, kc, N, nlev, self.keep_scale, 1, 0.7, 0, self.cap_p)
+            lib.fr_box_refine(_lib.ptr(b1), _lib.ptr(a1), 4, _lib.ptr(c1), N, self.cap_p, 0, self._s)
+            if trace is not None:
+                trace.update(stage1_boxes=b1, stage1_scores=s1, stage1_counts=c1)
+            # ---- stage 2
+            B2 = N * self.cap_p
+            crops = self._f32(B2, 24, 24, 3)
+            lib.fr_crop_resize_norm(_lib.ptr(frames), N, H, W, _lib.ptr(b1), _lib.ptr(c1), self.cap_p, 24,
+                                    _lib.ptr(crops), self._s)
+            head2 = self.rnet(crops, B2)
+            sb, ss, sa, sc = self._f32(N, self.cap_p, 4), self._f32(N, self.cap_p), self._f32(N, self.cap_p, 4), self._i32(N)
+            prob2 = self._f32(N, self.cap_p) if trace is not None else None
+            lib.fr_stage_select(_lib.ptr(b1), _lib.ptr(head2), 6, _lib.ptr(c1), N, self.cap_p, t1, _lib.ptr(sb),
+                                _lib.ptr(ss), _lib.ptr(sa), 4, _lib.ptr(sc), _lib.ptr(prob2), self._s)
+            b2, s2, a2, c2 = self._nms(sb, ss, sa, 4, sc, N, 1, self.cap_p, 0, 0.7, 0, self.cap_r)
+            lib.fr_box_refine(_lib.ptr(b2), _lib.ptr(a2), 4, _lib.ptr(c2), N, self.cap_r, 1, self._s)
+            if trace is not None:
+                trace.update(rnet_crops=crops, rnet_head=head2, rnet_prob=prob2, stage2_boxes=b2, stage2_scores=s2,
+                             stage2_counts=c2)
+            # ---- stage 3
+            B3 = N * self.cap_r
+            crops3 = self._f32(B3, 48, 48, 3)
+            lib.fr_crop_resize_norm(_lib.ptr(frames), N, H, W, _lib.ptr(b2), _lib.ptr(c2), self.cap_r, 48,
+                                    _lib.ptr(crops3), self._s)
+            head3 = self.onet(crops3, B3)
+            tb, ts, ta, tc = self._f32(N, self.cap_r, 4), self._f32(N, self.cap_r), self._f32(N, self.cap_r, 14), self._i32(N)
+            prob3 = self._f32(N, self.cap_r) if trace is not None else None
+            lib.fr_stage_select(_lib.ptr(b2), _lib.ptr(head3), 16, _lib.ptr(c2), N, self.cap_r, t2, _lib.ptr(tb),
+                                _lib.ptr(ts), _lib.ptr(ta), 14, _lib.ptr(tc), _lib.ptr(prob3), self._s)
+            lib.fr_box_refine(_lib.ptr(tb), _lib.ptr(ta), 14, _lib.ptr(tc), N, self.cap_r, 2, self._s)
+            b3, s3, a3, c3 = self._nms(tb, ts, ta, 14, tc, N, 1, self.cap_r, 0, 0.7, 1, self.cap_o)
+            if trace is not None:
+                trace.update(onet_head=head3, onet_prob=prob3)
+            # aux = (reg4, (x1,y1)..(x5,y5)): kps is a strided view, no copy
+            kps = a3[..., 4:14].unflatten(-1, (5, 2))
+        return b3, s3, kps, c3

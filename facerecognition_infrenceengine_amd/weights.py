@@ -78,7 +78,7 @@ def _mt_prelu(g, st, name, c):
 # ~half of all cells; these shift the 'face' logit so the cascade keeps a
 # realistic fraction at the standard 0.6/0.7/0.7 thresholds (calibrated on the
 # bench's synthetic frames; see DESIGN.md "Synthetic weights").
-SYNTH_FACE_LOGIT_BIAS = {"pnet": -3.9, "rnet": -1.2, "onet": -1.6}
+SYNTH_FACE_LOGIT_BIAS = {"pnet": -0.3, "rnet": -0.6, "onet": 1.75}
 
 
 def synth_mtcnn_states(seed=4321, face_logit_bias=None):

@@ -83,6 +83,69 @@ int fr_conv_nhwc_f16(const fr_conv_args* args, fr_stream_t stream);
 int fr_fc_reduce_l2norm(const float* partial, int splitk, int B, int dim, const float* bias,
                         float* embedding, float* normed, fr_stream_t stream);
 
+
+/* ---------------------------------------------------------------- align ----
+ * a-3  5-point similarity (closed-form least squares == Umeyama for proper rotations) and
+ * bilinear warpAffine to size x size, border 0, uint8 rounding, then (x-127.5)/127.5,
+ * BGR->RGB, NHWC f16 with C padded to 8 (the stem conv's packed input).  Stands in for
+ * insightface face_align.norm_crop inside FaceAnalysis.get (infrenceServer.py:528).
+ * frames: u8 [nframes,H,W,3] BGR; kps f32 [F,5,2]; frame_idx i32 [F]; count: device i32 (faces
+ * at index >= *count are zero-filled) or NULL; out_u8_bgr u8 [F,size,size,3] and
+ * M_out f32 [F,2,3] are optional. */
+int fr_warp_affine_5pt(const uint8_t* frames, int nframes, int H, int W, const float* kps,
+                       const int32_t* frame_idx, const int32_t* count, int F, int size,
+                       void* out_f16_nhwc8, uint8_t* out_u8_bgr, float* M_out, fr_stream_t stream);
+
+/* --------------------------------------------------------------- detect ----
+ * a-2  MTCNN cascade (detector half of FaceAnalysis.get, infrenceServer.py:528); the
+ * conventions (resize, ordering, capacities) are those of oracle/detect.py. */
+/* pyramid level: bilinear resize (half-pixel centres) + BGR->RGB + (x-127.5)*0.0078125 -> f32 NHWC(3) */
+int fr_pyramid_resize_norm(const uint8_t* frames, int nframes, int H, int W, int hs, int ws,
+                           float* out, fr_stream_t stream);
+/* direct valid conv, f32 NHWC, + bias + PReLU (slope may be NULL).  w: [KH][KW][Cin][CoutP] with
+ * CoutP = Cout rounded up to 16 (or 32), zero padded; bias/slope: [CoutP].
+ * pool2 != 0: fused 2x2/s2 ceil-mode max pool after the PReLU (P-Net conv1).
+ * nhead == 6: fused 1x1 head after the PReLU (P-Net conv3 -> conv4_1|conv4_2):
+ * y = [.., 6] = head_b + act . head_w[32][6]. */
+int fr_dconv_f32(const float* x, const float* w, const float* bias, const float* slope, float* y,
+                 int B, int H, int W, int Cin, int Cout, int CoutP, int KH, int KW, int pool2,
+                 const float* head_w, const float* head_b, int nhead, fr_stream_t stream);
+/* max pool, ceil mode, f32 NHWC */
+int fr_maxpool_f32(const float* x, float* y, int B, int H, int W, int C, int k, int stride,
+                   fr_stream_t stream);
+/* P-Net level -> per-frame candidate lists: head f32 [nframes,hc,wc,6] = (logit0, logit1, reg0..3);
+ * keeps cells with softmax face prob >= thr in raster order (first `cap`), emitting
+ * box = floor((2*cell + {1,12}) / scale), score, reg.  boxes [nframes,cap,4], scores [nframes,cap],
+ * regs [nframes,cap,4], counts i32 [nframes]; block_counts: i32 scratch [nframes*ceil(hc*wc/256)];
+ * prob_out (optional) f32 [nframes,hc,wc]. */
+int fr_pnet_candidates(const float* head, int nframes, int hc, int wc, float scale, float thr, int cap,
+                       float* boxes, float* scores, float* regs, int32_t* counts,
+                       int32_t* block_counts, float* prob_out, fr_stream_t stream);
+/* per-list sort (descending score, ties by slot) + greedy NMS (mode 0: IoU, 1: IoMin).
+ * Input list l = nseg segments of seg_cap slots (segment s at list index l*nseg+s, or s*L+l when
+ * seg_major), counts i32 [L*nseg] (nseg*seg_cap <= 4096);
+ * aux f32 [.., naux] rides along.  Output: first max_keep survivors in score order,
+ * boxes_out [L,cap_out,4], scores_out [L,cap_out], aux_out [L,cap_out,naux], counts_out [L]. */
+int fr_sort_nms(const float* boxes, const float* scores, const float* aux, int naux,
+                const int32_t* counts, int L, int nseg, int seg_cap, int seg_major, float thr, int mode,
+                int max_keep,
+                float* boxes_out, float* scores_out, float* aux_out, int32_t* counts_out,
+                int cap_out, fr_stream_t stream);
+/* box refinement in place, regs = aux[..,0:4]: mode 0 = stage-1 regression (w = x2-x1) + square;
+ * mode 1 = bbreg (w = x2-x1+1) + square; mode 2 = bbreg only. */
+int fr_box_refine(float* boxes, const float* aux, int naux, const int32_t* counts, int L, int cap,
+                  int mode, fr_stream_t stream);
+/* zero-padded crop of trunc(box) (1-based inclusive) + bilinear resize to size x size + normalise
+ * -> f32 NHWC(3) [nframes*cap,size,size,3]; slots >= count are zero-filled. */
+int fr_crop_resize_norm(const uint8_t* frames, int nframes, int H, int W, const float* boxes,
+                        const int32_t* counts, int cap, int size, float* out, fr_stream_t stream);
+/* R/O-Net decision: head f32 [L*cap,nh] = (logit0, logit1, reg0..3[, lm0..9]); keeps slots with
+ * softmax face prob > thr in slot order, emitting trunc(box), score, aux = (reg0..3[, landmarks
+ * (x1,y1)..(x5,y5) in frame coordinates]) (nh,naux) = (6,4) or (16,14). */
+int fr_stage_select(const float* boxes, const float* head, int nh, const int32_t* counts, int L, int cap,
+                    float thr, float* boxes_out, float* scores_out, float* aux_out, int naux,
+                    int32_t* counts_out, float* prob_out, fr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,8 @@ HIP kernels implement):
 * resize = bilinear, half-pixel centres, edge clamp, no antialias, float32;
 * candidate order = descending score, ties by slot index (stable);
 * fixed capacities (per frame): CAP_SCALE candidates per scale taken in raster
-  order before NMS, CAP_P boxes after stage 1, CAP_R after stage 2, CAP_O faces.
+  order before NMS, KEEP_SCALE survivors per scale, CAP_P boxes after stage 1,
+  CAP_R after stage 2, CAP_O faces (each the first K in score order).
 
 Test infrastructure only.
 """
@@ -132,7 +133,7 @@ def crop_resize(frame_rgb_f32, box_i, size):
 
 
 def detect(frame_bgr, pstate, rstate, ostate, minsize=20, factor=0.709,
-           thresholds=(0.6, 0.7, 0.7), cap_scale=2048, cap_p=512, cap_r=64, cap_o=16,
+           thresholds=(0.6, 0.7, 0.7), cap_scale=2048, keep_scale=256, cap_p=512, cap_r=64, cap_o=16,
            trace=None):
     """Returns (bbox float32[F,4], score float32[F], kps float32[F,5,2])."""
     H, W = frame_bgr.shape[:2]
@@ -161,7 +162,7 @@ def detect(frame_bgr, pstate, rstate, ostate, minsize=20, factor=0.709,
         b = np.stack([x1, y1, x2, y2], 1).astype(F32)
         r = reg[:, ys, xs].T.astype(F32)
         o = _order(sc); b, sc, r = b[o], sc[o], r[o]
-        k = nms(b, sc, 0.5, "union")
+        k = nms(b, sc, 0.5, "union")[:keep_scale]
         all_boxes.append(b[k]); all_scores.append(sc[k]); all_reg.append(r[k])
     empty = (np.zeros((0, 4), F32), np.zeros((0,), F32), np.zeros((0, 5, 2), F32))
     if not all_boxes:

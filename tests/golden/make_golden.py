@@ -239,7 +239,7 @@ def synth_frame(h, w, seed):
     img = 0.6 * F.interpolate(low, (h, w), mode="bicubic", align_corners=False) + \
         0.3 * F.interpolate(mid, (h, w), mode="bilinear", align_corners=False) + \
         0.1 * torch.from_numpy(rng.random((1, 3, h, w), dtype=np.float32))
-    return (img[0].permute(1, 2, 0).clamp(0, 1) * 255).round().to(torch.uint8).numpy()
+    return np.ascontiguousarray((img[0].permute(1, 2, 0).clamp(0, 1) * 255).round().to(torch.uint8).numpy())
 
 
 def make_nets():
@@ -263,9 +263,9 @@ def make_nets():
     sub = {k.replace(".", "_"): v[:, ::8, ::3, ::3].numpy() for k, v in taps.items()}
     np.savez_compressed(os.path.join(HERE, "r100_kat.npz"), seed=np.asarray([1234]), x=x.numpy(),
                         embedding=emb.numpy(), **{"tap_" + k: v for k, v in sub.items()})
-    # ---- mtcnn on one 160x120 frame
+    # ---- mtcnn on one 320x240 frame
     p, r, o = weights.synth_mtcnn_states(seed=4321)
-    fr = synth_frame(120, 160, 9)
+    fr = synth_frame(240, 320, 9)
     tr = {}
     b, s, k = detect.detect(fr, p, r, o, trace=tr)
     save = {"frame": fr, "bbox": b, "score": s, "kps": k, "seed": np.asarray([4321])}

@@ -1,0 +1,144 @@
+"""GPU parity: MTCNN cascade + 5-point alignment through the C ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import align as oalign
+from oracle import detect as odetect
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def det():
+    from facerecognition_infrenceengine_amd import weights
+    from facerecognition_infrenceengine_amd.mtcnn import MTCNNHIP
+    return MTCNNHIP(*weights.synth_mtcnn_states(seed=4321), device="cuda:0")
+
+
+def test_pyramid_scales_match_oracle():
+    from facerecognition_infrenceengine_amd.mtcnn import pyramid_scales
+    for h, w in ((480, 640), (1080, 1920), (2160, 3840), (120, 160), (13, 400)):
+        assert pyramid_scales(h, w) == odetect.pyramid_scales(h, w)
+    assert len(pyramid_scales(480, 640)) == 10 and len(pyramid_scales(1080, 1920)) == 12
+    assert len(pyramid_scales(2160, 3840)) == 14
+
+
+def test_pnet_maps_vs_golden(det, golden):
+    d = golden("mtcnn_kat.npz")
+    frame = torch.from_numpy(d["frame"]).cuda()[None].contiguous()
+    tr = {}
+    det.detect_batch(frame, trace=tr)
+    H, W = d["frame"].shape[:2]
+    assert len(tr["pnet_prob"]) == len(odetect.pyramid_scales(H, W))
+    for i, (prob, head) in enumerate(zip(tr["pnet_prob"], tr["pnet_head"])):
+        np.testing.assert_allclose(prob[0].cpu().numpy(), d[f"pnet_prob_{i}"], atol=2e-5)
+        reg = head[0, :, :, 2:6].permute(2, 0, 1).cpu().numpy()
+        np.testing.assert_allclose(reg, d[f"pnet_reg_{i}"], atol=2e-5)
+
+
+def _check_stage(got_b, got_s, want_b, want_s, atol_box):
+    assert len(got_s) == len(want_s), (len(got_s), len(want_s))
+    np.testing.assert_allclose(got_s, want_s, atol=5e-5)
+    np.testing.assert_allclose(got_b, want_b, atol=atol_box)
+
+
+def test_cascade_stages_vs_golden(det, golden):
+    d = golden("mtcnn_kat.npz")
+    frame = torch.from_numpy(d["frame"]).cuda()[None].contiguous()
+    tr = {}
+    boxes, scores, kps, counts = det.detect_batch(frame, trace=tr)
+    n1 = int(tr["stage1_counts"][0])
+    _check_stage(tr["stage1_boxes"][0, :n1].cpu().numpy(), tr["stage1_scores"][0, :n1].cpu().numpy(),
+                 d["stage1_boxes"], d["stage1_scores"], 2e-3)
+    # R-Net scores for every stage-1 candidate (slot order == oracle order)
+    np.testing.assert_allclose(tr["rnet_prob"][0, :n1].cpu().numpy(), d["rnet_score"], atol=5e-5)
+    n2 = int(tr["stage2_counts"][0])
+    _check_stage(tr["stage2_boxes"][0, :n2].cpu().numpy(), tr["stage2_scores"][0, :n2].cpu().numpy(),
+                 d["stage2_boxes"], d["stage2_scores"], 5e-3)
+    np.testing.assert_allclose(tr["onet_prob"][0, :n2].cpu().numpy(), d["onet_score"], atol=5e-5)
+    n3 = int(counts[0])
+    _check_stage(boxes[0, :n3].cpu().numpy(), scores[0, :n3].cpu().numpy(), d["bbox"], d["score"], 5e-3)
+    np.testing.assert_allclose(kps[0, :n3].cpu().numpy(), d["kps"], atol=5e-3)
+    assert n3 >= 1
+
+
+@pytest.mark.parametrize("hw,seed", [((96, 128), 3), ((240, 320), 21), ((13, 200), 1), ((21, 200), 1), ((480, 640), 0)])
+def test_cascade_vs_oracle_other_frames(det, hw, seed):
+    """Fresh seeded frames (incl. frames whose pyramid has zero / one level and the 640x480 C1 case)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import synth_frame
+    from facerecognition_infrenceengine_amd import weights
+    fr = synth_frame(hw[0], hw[1], seed)
+    p, r, o = weights.synth_mtcnn_states(seed=4321)
+    ob, os_, ok = odetect.detect(fr, p, r, o)
+    boxes, scores, kps, counts = det.detect_batch(torch.from_numpy(fr).cuda()[None].contiguous())
+    n = int(counts[0])
+    assert n == len(os_)
+    if n:
+        np.testing.assert_allclose(scores[0, :n].cpu().numpy(), os_, atol=5e-5)
+        np.testing.assert_allclose(boxes[0, :n].cpu().numpy(), ob, atol=5e-3)
+        np.testing.assert_allclose(kps[0, :n].cpu().numpy(), ok, atol=5e-3)
+
+
+def test_batch_equals_single_frames(det):
+    """Frames of a batch are independent (property used for sharding frames across GPUs)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import synth_frame
+    frs = np.ascontiguousarray(np.stack([synth_frame(120, 160, s) for s in (1, 2, 3)]))
+    bb, ss, kk, cc = det.detect_batch(torch.from_numpy(frs).cuda())
+    for i in range(3):
+        b1, s1, k1, c1 = det.detect_batch(torch.from_numpy(frs[i:i + 1]).cuda())
+        assert int(c1[0]) == int(cc[i])
+        n = int(c1[0])
+        assert torch.equal(b1[0, :n], bb[i, :n]) and torch.equal(s1[0, :n], ss[i, :n])
+
+
+def test_nms_kernel_vs_oracle(lib):
+    from facerecognition_infrenceengine_amd import _lib
+    rng = np.random.default_rng(5)
+    for n, cap, mode, thr in ((0, 64, 0, 0.5), (1, 64, 0, 0.5), (300, 512, 0, 0.5), (1500, 2048, 0, 0.7),
+                              (64, 64, 1, 0.7), (3000, 4096, 0, 0.7)):
+        c = rng.uniform(0, 300, (n, 2)); wh = rng.uniform(10, 80, (n, 2))
+        boxes = np.zeros((cap, 4), np.float32)
+        boxes[:n] = np.floor(np.concatenate([c, c + wh], 1)).astype(np.float32)
+        scores = np.zeros(cap, np.float32); scores[:n] = rng.uniform(0.6, 1.0, n).astype(np.float32)
+        if n > 10:
+            scores[5] = scores[9]                                  # exact score tie -> slot order
+        order = np.argsort(-scores[:n], kind="stable")
+        keep = odetect.nms(boxes[:n][order], scores[:n][order], thr, "min" if mode else "union")
+        want = order[keep][:256]
+        bd, sd = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+        aux = torch.arange(cap, dtype=torch.float32, device="cuda").reshape(cap, 1).contiguous()
+        cnt = torch.tensor([n], dtype=torch.int32, device="cuda")
+        bo = torch.empty((1, 256, 4), device="cuda"); so = torch.empty((1, 256), device="cuda")
+        ao = torch.empty((1, 256, 1), device="cuda"); co = torch.empty(1, dtype=torch.int32, device="cuda")
+        lib.fr_sort_nms(_lib.ptr(bd), _lib.ptr(sd), _lib.ptr(aux), 1, _lib.ptr(cnt), 1, 1, cap, 0, thr, mode, 256,
+                        _lib.ptr(bo), _lib.ptr(so), _lib.ptr(ao), _lib.ptr(co), 256, _lib.stream_ptr())
+        k = int(co[0])
+        assert k == len(want)
+        assert np.array_equal(ao[0, :k, 0].cpu().numpy().astype(np.int64), want)   # identical survivors, identical order
+
+
+def test_align_vs_golden(lib, golden):
+    from facerecognition_infrenceengine_amd import _lib
+    d = golden("align_kat.npz")
+    frame = torch.from_numpy(d["frame"]).cuda()[None].contiguous()
+    kps = torch.from_numpy(d["kps"]).cuda()
+    F = kps.shape[0]
+    H, W = d["frame"].shape[:2]
+    fidx = torch.zeros(F, dtype=torch.int32, device="cuda")
+    out = torch.empty((F, 112, 112, 8), dtype=torch.float16, device="cuda")
+    u8 = torch.empty((F, 112, 112, 3), dtype=torch.uint8, device="cuda")
+    M = torch.empty((F, 2, 3), dtype=torch.float32, device="cuda")
+    lib.fr_warp_affine_5pt(_lib.ptr(frame), 1, H, W, _lib.ptr(kps), _lib.ptr(fidx), None, F, 112, _lib.ptr(out),
+                           _lib.ptr(u8), _lib.ptr(M), _lib.stream_ptr())
+    np.testing.assert_allclose(M.cpu().numpy(), d["M"], rtol=1e-5, atol=1e-4)     # closed form == Umeyama SVD
+    diff = np.abs(u8.cpu().numpy().astype(int) - d["crops"].astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3                            # uint8 rounding at exact .5 only
+    want = np.stack([oalign.crop_to_net(c) for c in u8.cpu().numpy()])            # [F,3,112,112] RGB
+    got = out[..., :3].float().cpu().numpy().transpose(0, 3, 1, 2)
+    np.testing.assert_allclose(got, want, atol=1e-3)                               # f16 storage
+    assert float(out[..., 3:].abs().max()) == 0.0
