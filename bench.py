@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: faces/sec end-to-end at 1080p (BASELINE.json metric, config C2).
+
+One step = one batch of 64 synthetic 1080p BGR frames, resident in HBM, through the whole hot
+path on one GPU: MTCNN pyramid + NMS -> 5-point warp -> ArcFace IResNet-100 (f16 MFMA) ->
+gallery match against 10 000 rows, ids on the host at the end of the step.  With N ranks each
+GPU processes its own 64-frame batch (weak scaling); the gallery is row-sharded and the
+embedding rows are all-gathered over RCCL before the shared match.
+
+Prints ONE JSON line (rank 0).  `roofline` is the dominant kernel (the IResNet body conv on
+MFMA), timed with HIP events on its launch stream in an instrumented pass after the timed region;
+`cpu_baseline` is the CPU oracle (a port, not the reference) timed on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FRAMES, H, W = 64, 1080, 1920
+GALLERY_ROWS = 10_000
+FACES_PER_FRAME = 4                    # O-Net cap (C2 keeps F = 4 -> 256 faces/batch)
+MFMA_PEAK_TFLOPS = 2500.0              # dense f16/bf16 (MI355X_MICROARCH.md)
+
+
+def synth_frames(n, h, w, seed, device):
+    """Structured synthetic BGR frames (low-pass + mid + fine noise), uint8, generated on device."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    import torch.nn.functional as F
+    low = torch.rand((n, 3, h // 16, w // 16), generator=g, device=device)
+    mid = torch.rand((n, 3, h // 4, w // 4), generator=g, device=device)
+    img = 0.6 * F.interpolate(low, (h, w), mode="bicubic", align_corners=False) \
+        + 0.3 * F.interpolate(mid, (h, w), mode="bilinear", align_corners=False) \
+        + 0.1 * torch.rand((n, 3, h, w), generator=g, device=device)
+    return (img.permute(0, 2, 3, 1).clamp(0, 1) * 255).round().to(torch.uint8).contiguous()
+
+
+def cpu_baseline(n_frames, rows):
+    """CPU oracle on a bounded sample of the same workload (rank 0, N == 1 only)."""
+    from facerecognition_infrenceengine_amd import weights
+    from oracle import align as oalign, detect as odetect, match as omatch, nets as onets
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden import synth_frame
+    cores = torch.get_num_threads()
+    p, r, o = weights.synth_mtcnn_states()
+    st = weights.synth_iresnet_state("r100")
+    rng = np.random.default_rng(1)
+    G = rng.standard_normal((rows, 512)).astype(np.float32)
+    G /= np.linalg.norm(G, axis=1, keepdims=True)
+    gal = {i: G[i] for i in range(rows)}
+    frames = [synth_frame(H, W, 100 + i) for i in range(n_frames)]
+    t0 = time.perf_counter()
+    faces = 0
+    for fr in frames:
+        b, s, k = odetect.detect(fr, p, r, o, cap_o=FACES_PER_FRAME)
+        if len(s) == 0:
+            continue
+        crops = [oalign.norm_crop(fr, kk)[0] for kk in k]
+        x = torch.from_numpy(np.stack([oalign.crop_to_net(c) for c in crops]))
+        emb = onets.iresnet_forward(st, x, weights.IRESNET_LAYERS["r100"]).numpy()
+        for e in emb:
+            q = omatch.renormalise(e / np.linalg.norm(e))
+            omatch.decide_live(*omatch.linear_scan(q, gal))          # literal per-row Python loop
+            faces += 1
+    dt = time.perf_counter() - t0
+    return {"value": faces / dt, "unit": "faces/s", "cores": cores, "kind": "port",
+            "sample": f"{n_frames} synthetic 1080p frames, {faces} faces, r100 fp32 torch-CPU + literal "
+                      f"{rows}-row Python match loop, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=4)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    device = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import warnings
+    from facerecognition_infrenceengine_amd import FaceAnalysis, GalleryMatcher
+    from facerecognition_infrenceengine_amd.distributed import ShardedGalleryMatcher, shard_rows
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        app = FaceAnalysis(name="synthetic", arch="r100", cap_o=FACES_PER_FRAME)
+        app.prepare(ctx_id=local_rank)
+
+    # gallery: seed-1 unit rows, row-sharded over the ranks
+    g = torch.Generator(device=device).manual_seed(1)
+    G = torch.randn((GALLERY_ROWS, 512), generator=g, device=device)
+    lo, hi = shard_rows(GALLERY_ROWS, world, rank)
+    gm = GalleryMatcher(device)
+    gm.set_rows(range(lo, hi), G[lo:hi].contiguous(), normalise=True)
+    q_max = FRAMES * FACES_PER_FRAME
+    sharded = ShardedGalleryMatcher(lambda Q: gm.match_device(Q, renormalise=True, row_offset=lo), q_max)
+
+    nbatch = min(max(args.steps, 1), 3)
+    batches = [synth_frames(FRAMES, H, W, rank * 1000 + i, device) for i in range(nbatch)]
+
+    def step(i):
+        r = app.detect_embed_device(batches[i % nbatch])
+        idx, score = sharded.match(r["normed_embedding"])
+        dec = gm.decide_device(idx, score, 0.4)
+        return idx.cpu(), dec.cpu(), len(idx)            # ids on the host = end of the step
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    faces = 0
+    for i in range(args.steps):
+        faces += step(i)[2]
+    sync()
+    dt = time.perf_counter() - t0
+    tot = torch.tensor([dt, float(faces)], dtype=torch.float64, device=device)
+    if world > 1:
+        tmax = tot.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tot.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, faces = float(tmax[0]), float(tsum[1])
+
+    # ---- instrumented pass (outside the timed region): HIP events around every conv launch
+    app.rec.profile = []
+    r = app.detect_embed_device(batches[0])
+    torch.cuda.synchronize()
+    per = {}
+    for variant, flops, e0, e1 in app.rec.profile:
+        d = per.setdefault(variant, [0, 0.0, 0.0])
+        d[0] += 1; d[1] += flops; d[2] += e0.elapsed_time(e1) * 1e-3
+    app.rec.profile = None
+    dom = max(per, key=lambda k: per[k][2])
+    calls, flops, secs = per[dom]
+    achieved = flops / secs / 1e12
+    roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": calls, "avg_launch_us": round(secs / calls * 1e6, 2),
+                "algorithmic_gflop_per_launch": round(flops / calls / 1e9, 3)}
+
+    if rank == 0:
+        out = {"metric": "faces/sec end-to-end @1080p", "value": round(faces / dt, 1), "unit": "faces/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+               "config": {"workload": "C2: 64x1080p synthetic frames/GPU, MTCNN full pyramid (caps 512/64/4), "
+                                      "ArcFace r100 f16 embed, 10k-row cosine gallery (row-sharded over ranks)",
+                          "frames_per_step_per_gpu": FRAMES, "faces_per_step": faces / args.steps,
+                          "gallery_rows": GALLERY_ROWS, "weights": "seeded synthetic",
+                          "parallelism": f"frame-shard x{world} + gallery row-shard"},
+               "per_face_latency_ms": round(dt / max(faces / world, 1) * 1e3, 4),
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_frames, GALLERY_ROWS)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,72 @@
+"""Multi-GPU match: frames are sharded across ranks (one process per GPU), the gallery is
+row-sharded, and one exchange step joins them.
+
+The reference's only parallelism is one OS process per camera, each scanning the whole gallery
+(/root/reference/infrenceServer.py:606,641-646).  Here:
+
+  1. all-gather of the per-rank query rows, padded to ``q_max`` with a count  (RCCL over xGMI;
+     payload is KBs, so it is latency-bound: one collective, no bucketing);
+  2. every rank scans ITS gallery shard for ALL gathered queries (one HBM pass over the shard);
+  3. all-gather of the per-shard (score, global row) pairs; each rank reduces the candidates of
+     its own queries: maximum score, lowest global row on exact ties - the same rule as the
+     single-GPU scan (strict '>' in /root/reference/infrenceServer.py:538-542).
+
+``local_scan(Q[F,512]) -> (idx int64[F] global rows or -1, score f32[F])`` is injected: the
+product passes the HIP scan (GalleryMatcher.match_device with row_offset), the CPU ``gloo`` tests
+pass the oracle.  This module contains no arithmetic besides the final max/tie reduce.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_rows(n_rows, world_size, rank):
+    """Contiguous row shard [lo, hi) of rank; the first n_rows % world ranks get one extra row."""
+    base, rem = divmod(n_rows, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def reduce_candidates(scores, idx):
+    """scores f32 [R,F], idx i64 [R,F] (global rows, -1 = none) -> best (idx[F], score[F]):
+    maximum score, lowest row index on exact ties; (-1, -1.0) when no shard has a candidate."""
+    valid = idx >= 0
+    s = torch.where(valid, scores, torch.full_like(scores, float("-inf")))
+    best = s.max(dim=0).values
+    big = torch.iinfo(torch.int64).max
+    cand = torch.where(valid & (s == best[None, :]), idx, torch.full_like(idx, big))
+    bi = cand.min(dim=0).values
+    none = bi == big
+    return torch.where(none, torch.full_like(bi, -1), bi), torch.where(none, torch.full_like(best, -1.0), best)
+
+
+class ShardedGalleryMatcher:
+    def __init__(self, local_scan, q_max, dim=512, group=None):
+        self.local_scan, self.q_max, self.dim, self.group = local_scan, q_max, dim, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def match(self, Q):
+        """Q f32 [F_local,dim] on this rank's device (F_local <= q_max).
+        Returns (idx i64[F_local] global rows, score f32[F_local]) for the local queries."""
+        F = Q.shape[0]
+        assert F <= self.q_max, "more local queries than q_max"
+        if self.world == 1:
+            return self.local_scan(Q)
+        dev = Q.device
+        # (1) gather queries; the count rides in an extra row so it stays ONE collective
+        send = torch.zeros((self.q_max + 1, self.dim), dtype=torch.float32, device=dev)
+        send[:F] = Q
+        send[self.q_max, 0] = float(F)
+        allq = torch.empty((self.world * (self.q_max + 1), self.dim), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(allq, send, group=self.group)      # concatenated along dim 0
+        allq = allq.view(self.world, self.q_max + 1, self.dim)
+        # (2) scan the local shard for every gathered query (padding rows included: fixed shape)
+        flat = allq[:, :self.q_max].reshape(self.world * self.q_max, self.dim)
+        idx, score = self.local_scan(flat)
+        # (3) gather the per-shard candidates and reduce those of the local queries
+        pair = torch.stack([score.to(torch.float64), idx.to(torch.float64)], dim=1).contiguous()
+        allp = torch.empty((self.world * pair.shape[0], 2), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allp, pair, group=self.group)
+        allp = allp.view(self.world, pair.shape[0], 2)
+        mine = allp[:, self.rank * self.q_max:self.rank * self.q_max + F]
+        return reduce_candidates(mine[..., 0].to(torch.float32), mine[..., 1].to(torch.int64))

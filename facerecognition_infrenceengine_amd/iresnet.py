@@ -103,6 +103,7 @@ class IResNetHIP:
         self.fc_w = Wf.to(torch.float16).contiguous().to(dev)
         self.fc_bias = bias.to(torch.float32).contiguous().to(dev)
         self.flops_per_face = self._count_flops()
+        self.profile = None          # bench.py: list collecting (kernel variant, flops, ev0, ev1) per conv launch
 
     def _count_flops(self):
         f, hw = 2 * 112 * 112 * 27 * 64, 112
@@ -124,7 +125,17 @@ class IResNetHIP:
         a = _lib.ConvArgs(_lib.ptr(x), _lib.ptr(c.w) if isinstance(c, _Conv) else None, _lib.ptr(y),
                           _lib.ptr(c.bias), _lib.ptr(c.slope), _lib.ptr(residual), _lib.ptr(partial),
                           B, H, W, c.cin, c.cout, c.k, c.k, c.stride, c.pad, Ho, Wo, c.bias_mode, splitk)
-        self.lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
+        if self.profile is not None:
+            # HIP events on the stream the kernel is launched on (torch's current stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
+            e1.record()
+            variant = "conv_mfma_kernel<%d, %s>" % (2 if c.cout % 128 == 0 else 1, "true" if c.cin == 8 else "false")
+            kreal = 27 if c.cin == 8 else c.k * c.k * c.cin       # algorithmic K (stem: 3 real channels)
+            self.profile.append((variant, 2.0 * B * Ho * Wo * c.cout * kreal, e0, e1))
+        else:
+            self.lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
         return y, Ho, Wo
 
     def forward(self, x, taps=None):

@@ -1,0 +1,94 @@
+"""world_size-2 gloo test of the frame-sharded / gallery-row-sharded match exchange (host logic);
+the local scan is the oracle here (the product wires the HIP scan into the same class)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import match as omatch
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, G, Qs, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from facerecognition_infrenceengine_amd.distributed import ShardedGalleryMatcher, shard_rows
+    lo, hi = shard_rows(len(G), world, rank)
+    shard = G[lo:hi]
+
+    def local_scan(Q):
+        idx, score = omatch.match_rows_fast(Q.numpy(), shard) if len(shard) else (
+            np.full(len(Q), -1, np.int64), np.full(len(Q), -1, np.float32))
+        idx = np.where(idx >= 0, idx + lo, -1)
+        return torch.from_numpy(idx), torch.from_numpy(score)
+    m = ShardedGalleryMatcher(local_scan, q_max=8)
+    idx, score = m.match(torch.from_numpy(Qs[rank]))
+    out[rank] = (idx.numpy(), score.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, N, fs):
+    rng = np.random.default_rng(42 + N)
+    G = rng.standard_normal((N, 512)).astype(np.float32)
+    if N:
+        G /= np.linalg.norm(G, axis=1, keepdims=True)
+    Qs = []
+    for f in fs:
+        Q = rng.standard_normal((f, 512)).astype(np.float32)
+        Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+        Qs.append(Q)
+    if N > 40:
+        G[3] = Qs[0][0]; G[N - 2] = Qs[0][0]          # duplicate rows in DIFFERENT shards: lowest row wins
+        G[N - 5] = Qs[1][1] if fs[1] > 1 else G[N - 5]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), G, Qs, out), nprocs=world, join=True)
+    for r in range(world):
+        idx, score = out[r]
+        if N == 0:
+            assert (idx == -1).all()
+            continue
+        oi, os_ = omatch.match_rows_fast(Qs[r], G)
+        assert np.array_equal(idx, oi), (r, idx, oi)
+        np.testing.assert_allclose(score, os_, atol=1e-6)
+    return out
+
+
+def test_world2_sharded_match_equals_unsharded():
+    out = _run(2, 101, [5, 3])
+    assert out[0][0][0] == 3
+
+
+def test_world2_ragged_and_empty_rank():
+    _run(2, 64, [8, 0])        # one rank has no faces this step
+    _run(2, 1, [2, 2])         # one shard is empty (1 row over 2 ranks)
+
+
+def test_world4_matches_unsharded():
+    _run(4, 257, [1, 8, 0, 4])
+
+
+def test_shard_rows_partition():
+    from facerecognition_infrenceengine_amd.distributed import shard_rows
+    for n in (0, 1, 7, 10000, 1000003):
+        for w in (1, 2, 4, 8):
+            edges = [shard_rows(n, w, r) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
+
+
+def test_reduce_candidates_tie_rule():
+    from facerecognition_infrenceengine_amd.distributed import reduce_candidates
+    s = torch.tensor([[0.5, 0.9, -1.0], [0.5, 0.2, -1.0]])
+    i = torch.tensor([[40, 7, -1], [12, 99, -1]])
+    bi, bs = reduce_candidates(s, i)
+    assert bi.tolist() == [12, 7, -1]
+    assert torch.equal(bs, torch.tensor([0.5, 0.9, -1.0]))
