@@ -1,0 +1,303 @@
+// Detector convolutions (MTCNN P/R/O-Net, inside FaceAnalysis.get: /root/reference/infrenceServer.py:528)
+// as LDS-tiled implicit GEMMs on the f32-input matrix instruction v_mfma_f32_16x16x4_f32.
+//
+// Why f32 MFMA: the cascade thresholds scores (0.6/0.7/0.7) and floors box corners, so the
+// detector keeps f32 operands end to end (an f16 P-Net flips borderline cells and moves crops);
+// v_mfma_f32_16x16x4_f32 is an exact f32 fma chain at the f32 vector peak rate (64 FLOP/clk/SIMD)
+// without the VALU's per-FMA operand traffic.  These nets have 3..256 channels: the kernels are
+// bound by that f32 matrix rate / LDS feeding, not by the 2.5 PF f16 roof.
+//
+// GEMM view per block:  C[cout][pixel] = sum_{tap,ci} W[tap][ci][cout] * X[pixel + tap][ci]
+//   A operand = weights: lane (i = l&15, kq = l>>4) supplies W[k0+kq][cout0+i]   (LDS, [k][CP])
+//   B operand = pixels : lane (j = l&15, kq)        supplies X[pixel j][k0+kq]   (LDS input tile)
+//   C: lane holds pixel j, couts 4*kq .. 4*kq+3 of each 16-cout tile -> 16-byte NHWC stores.
+// Input tile: G images x (RH+KH-1) x (RW+KW-1) pixels, channel stride CINS = odd (bank spread),
+// channels padded to a multiple of 4 with zeros.  Weights are staged per group of TG taps.
+// Optional fused epilogues: PReLU, 2x2/s2 ceil-mode max pool (P-Net conv1), 1x1 head (P-Net
+// conv3 -> 2 logits + 4 regressions).
+#include "common.h"
+
+struct DcArgs {
+    const float* x; const float* w; const float* bias; const float* slope; float* y;
+    const float* head_w; const float* head_b;
+    int B, H, W;          // input images
+    int Ho, Wo;           // conv output extent (H-KH+1, W-KW+1)
+    int regions_x;        // regions per image row
+};
+
+template <int CIN, int COUT, int KH, int KW, int RH, int RW, int G, int NTB, int WN, int TG, bool POOL2, int NHEAD>
+struct DcCfg {
+    static constexpr int CINP = (CIN + 3) / 4 * 4;
+    static constexpr int CINS = CINP + 1;
+    static constexpr int IH = RH + KH - 1, IW = RW + KW - 1;
+    static constexpr int IMG = IH * IW * CINS;
+    static constexpr int CP = NTB * 16 + ((NTB % 2 == 0) ? 16 : 0);
+    static constexpr int NTAPS = KH * KW;
+    static constexpr int NSTAGE = NTAPS / TG;
+    static constexpr int WM = 4 / WN, NT = NTB / WN;
+    static constexpr int NPIX = G * RH * RW;
+    static constexpr int TP = (NPIX + 15) / 16;
+    static constexpr int PT = (TP + WM - 1) / WM;
+    static constexpr int LDS_FLOATS = G * IMG + TG * CINP * CP;
+    static_assert(NTAPS % TG == 0, "TG must divide the tap count");
+    static_assert(NTB % WN == 0 && (WN == 1 || WN == 2 || WN == 4), "bad wave split");
+    static_assert(!POOL2 || (RW % 16 == 0 && RH % 2 == 0 && G == 1 && WN == 1 && (RH * RW / 16) % 4 == 0), "pool layout");
+};
+
+template <int CIN, int COUT, int KH, int KW, int RH, int RW, int G, int NTB, int WN, int TG, bool POOL2, int NHEAD>
+__global__ __launch_bounds__(256) void dconv_mfma(DcArgs a) {
+    using C = DcCfg<CIN, COUT, KH, KW, RH, RW, G, NTB, WN, TG, POOL2, NHEAD>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xin = lds;
+    float* wl = lds + G * C::IMG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WN, wm = wave / WN;
+    const int li = lane & 15, kq = lane >> 4;
+    const int ry = blockIdx.x / a.regions_x, rx = blockIdx.x - ry * a.regions_x;
+    const int y0 = ry * RH, x0 = rx * RW;
+    const int img0 = blockIdx.z * G;
+    const int cg = blockIdx.y;
+
+    // ---- stage the input tile (zero outside the image / beyond CIN)
+    for (int e = tid; e < G * C::IMG; e += 256) {
+        const int g = e / C::IMG, r = e - g * C::IMG;
+        const int pix = r / C::CINS, ci = r - pix * C::CINS;
+        const int iy = pix / C::IW, ix = pix - iy * C::IW;
+        const int n = img0 + g, yy = y0 + iy, xx = x0 + ix;
+        float v = 0.f;
+        if (ci < CIN && n < a.B && yy < a.H && xx < a.W) v = a.x[(((int64_t)n * a.H + yy) * a.W + xx) * CIN + ci];
+        xin[e] = v;
+    }
+    // ---- per-lane pixel bases
+    int base[C::PT];
+#pragma unroll
+    for (int t = 0; t < C::PT; ++t) {
+        const int p = (wm * C::PT + t) * 16 + li;
+        int b = 0;
+        if (p < C::NPIX) {
+            const int g = p / (RH * RW), q = p - g * (RH * RW);
+            const int ty = q / RW, tx = q - ty * RW;
+            b = g * C::IMG + (ty * C::IW + tx) * C::CINS;
+        }
+        base[t] = b + kq;
+    }
+    float4v acc[C::NT][C::PT];
+#pragma unroll
+    for (int i = 0; i < C::NT; ++i)
+#pragma unroll
+        for (int t = 0; t < C::PT; ++t) acc[i][t] = float4v{0.f, 0.f, 0.f, 0.f};
+
+    const float* wsrc = a.w + (int64_t)cg * C::NTAPS * C::CINP * C::CP;
+    for (int st = 0; st < C::NSTAGE; ++st) {
+        if (st > 0) __syncthreads();
+        for (int e = tid; e < TG * C::CINP * C::CP; e += 256) wl[e] = wsrc[(int64_t)st * TG * C::CINP * C::CP + e];
+        __syncthreads();
+#pragma unroll
+        for (int tl = 0; tl < TG; ++tl) {
+            const int tap = st * TG + tl;
+            const int kh = tap / KW, kw = tap - kh * KW;
+            const int toff = (kh * C::IW + kw) * C::CINS;
+            const float* wt = wl + (tl * C::CINP + kq) * C::CP + wn * C::NT * 16 + li;
+#pragma unroll
+            for (int c4 = 0; c4 < C::CINP / 4; ++c4) {
+                float av[C::NT], bv[C::PT];
+#pragma unroll
+                for (int i = 0; i < C::NT; ++i) av[i] = wt[c4 * 4 * C::CP + i * 16];
+#pragma unroll
+                for (int t = 0; t < C::PT; ++t) bv[t] = xin[base[t] + toff + c4 * 4];
+#pragma unroll
+                for (int i = 0; i < C::NT; ++i)
+#pragma unroll
+                    for (int t = 0; t < C::PT; ++t)
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[t], acc[i][t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: bias + PReLU
+    const int coW = (cg * NTB + wn * C::NT) * 16 + kq * 4;      // first cout of this lane in tile i: coW + i*16
+#pragma unroll
+    for (int i = 0; i < C::NT; ++i) {
+        const float4v bv = *reinterpret_cast<const float4v*>(a.bias + coW + i * 16);
+        float4v sv = {1.f, 1.f, 1.f, 1.f};
+        if (a.slope) sv = *reinterpret_cast<const float4v*>(a.slope + coW + i * 16);
+#pragma unroll
+        for (int t = 0; t < C::PT; ++t) {
+            float4v v = acc[i][t] + bv;
+            if (a.slope) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * sv[e];
+            }
+            acc[i][t] = v;
+        }
+    }
+
+    if constexpr (POOL2) {
+        // tiles: t = 2*row_in_wave + half; wave owns rows wm*(PT/2) ..; pool rows (2a, 2a+1), lanes (2b, 2b+1)
+        constexpr int TR = RW / 16;                 // tiles per region row
+        const int Hp = (a.Ho + 1) / 2, Wp = (a.Wo + 1) / 2;
+#pragma unroll
+        for (int i = 0; i < C::NT; ++i) {
+#pragma unroll
+            for (int t = 0; t < C::PT; ++t) {
+                const int tile = wm * C::PT + t;
+                const int ty = tile / TR, tx = (tile - ty * TR) * 16 + li;
+                if (y0 + ty >= a.Ho || x0 + tx >= a.Wo) acc[i][t] = float4v{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            }
+            constexpr int ROWS = C::PT / TR;            // region rows owned by this wave (even)
+            static_assert(ROWS % 2 == 0, "a wave must own whole row pairs");
+#pragma unroll
+            for (int rp = 0; rp < ROWS / 2; ++rp) {
+#pragma unroll
+                for (int hf = 0; hf < TR; ++hf) {
+                    const int t = 2 * rp * TR + hf;      // even row; partner row is tile t + TR
+                    float4v v = acc[i][t];
+                    const float4v u = acc[i][t + TR];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float m = fmaxf(v[e], u[e]);
+                        float o = __shfl_xor(m, 1, 64);
+                        v[e] = fmaxf(m, o);
+                    }
+                    const int ty = wm * ROWS + 2 * rp;
+                    const int tx = hf * 16 + li;
+                    const int py = (y0 + ty) >> 1, px = (x0 + tx) >> 1;
+                    const int n = img0;
+                    if ((li & 1) == 0 && py < Hp && px < Wp && n < a.B) {
+                        float* o = a.y + (((int64_t)n * Hp + py) * Wp + px) * COUT;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (coW + i * 16 + e < COUT) o[coW + i * 16 + e] = v[e];
+                    }
+                }
+            }
+        }
+    } else if constexpr (NHEAD > 0) {
+        // y[pixel][h] = head_b[h] + sum_c act[c] * head_w[c][h]; lane has 4*NT of the channels
+#pragma unroll
+        for (int t = 0; t < C::PT; ++t) {
+            float h[NHEAD];
+#pragma unroll
+            for (int k = 0; k < NHEAD; ++k) h[k] = 0.f;
+#pragma unroll
+            for (int i = 0; i < C::NT; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = coW + i * 16 + e;
+#pragma unroll
+                    for (int k = 0; k < NHEAD; ++k) h[k] = __builtin_fmaf(acc[i][t][e], a.head_w[c * NHEAD + k], h[k]);
+                }
+#pragma unroll
+            for (int k = 0; k < NHEAD; ++k) {
+                h[k] += __shfl_xor(h[k], 16, 64);
+                h[k] += __shfl_xor(h[k], 32, 64);
+                h[k] += a.head_b[k];
+            }
+            const int p = (wm * C::PT + t) * 16 + li;
+            if (kq == 0 && p < C::NPIX) {
+                const int g = p / (RH * RW), q = p - g * (RH * RW);
+                const int ty = q / RW, tx = q - ty * RW;
+                const int n = img0 + g, oy = y0 + ty, ox = x0 + tx;
+                if (n < a.B && oy < a.Ho && ox < a.Wo) {
+                    float* o = a.y + (((int64_t)n * a.Ho + oy) * a.Wo + ox) * NHEAD;
+#pragma unroll
+                    for (int k = 0; k < NHEAD; ++k) o[k] = h[k];
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < C::PT; ++t) {
+            const int p = (wm * C::PT + t) * 16 + li;
+            if (p >= C::NPIX) continue;
+            const int g = p / (RH * RW), q = p - g * (RH * RW);
+            const int ty = q / RW, tx = q - ty * RW;
+            const int n = img0 + g, oy = y0 + ty, ox = x0 + tx;
+            if (n >= a.B || oy >= a.Ho || ox >= a.Wo) continue;
+            float* o = a.y + (((int64_t)n * a.Ho + oy) * a.Wo + ox) * COUT;
+#pragma unroll
+            for (int i = 0; i < C::NT; ++i) {
+                const int co = coW + i * 16;
+                if constexpr (COUT % 4 == 0) {
+                    if (co < COUT) *reinterpret_cast<float4v*>(o + co) = acc[i][t];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < COUT) o[co + e] = acc[i][t][e];
+                }
+            }
+        }
+    }
+}
+
+template <int CIN, int COUT, int KH, int KW, int RH, int RW, int G, int NTB, int WN, int TG, bool POOL2, int NHEAD>
+static int launch_dc(const DcArgs& a0, hipStream_t s) {
+    using C = DcCfg<CIN, COUT, KH, KW, RH, RW, G, NTB, WN, TG, POOL2, NHEAD>;
+    DcArgs a = a0;
+    a.Ho = a.H - KH + 1; a.Wo = a.W - KW + 1;
+    a.regions_x = (a.Wo + RW - 1) / RW;
+    const int regions_y = (a.Ho + RH - 1) / RH;
+    constexpr int COUTP = (COUT + 15) / 16 * 16;
+    static_assert(COUTP % (NTB * 16) == 0, "cout groups must tile COUTP");
+    dim3 grid(a.regions_x * regions_y, COUTP / (NTB * 16), (a.B + G - 1) / G);
+    const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+    auto kern = dconv_mfma<CIN, COUT, KH, KW, RH, RW, G, NTB, WN, TG, POOL2, NHEAD>;
+    if (lds > 64 * 1024) {
+        static bool done = false;       // attribute is per function; benign race (idempotent)
+        if (!done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess) {
+                fr_set_error("fr_dconv_mfma_f32: cannot raise dynamic LDS to %zu bytes", lds);
+                return FR_E_LAUNCH;
+            }
+            done = true;
+        }
+    }
+    kern<<<grid, 256, lds, s>>>(a);
+    return FR_OK;
+}
+
+// Layer table (see mtcnn.py: layer ids).  Geometry is fixed by the MTCNN architecture.
+extern "C" int fr_dconv_mfma_f32(int layer, const float* x, const float* w, const float* bias, const float* slope,
+                                 float* y, int B, int H, int W, const float* head_w, const float* head_b,
+                                 fr_stream_t stream) {
+    FR_REQUIRE(x && w && bias && y && B > 0 && H > 0 && W > 0, "fr_dconv_mfma_f32: bad argument");
+    DcArgs a{x, w, bias, slope, y, head_w, head_b, B, H, W, 0, 0, 0};
+    hipStream_t s = fr_stream(stream);
+    int rc = FR_OK;
+    switch (layer) {
+        //                    CIN COUT KH KW RH  RW  G  NTB WN TG  POOL2  NHEAD
+        case 0:  FR_REQUIRE(H >= 3 && W >= 3, "P1 input too small");
+                 rc = launch_dc<3, 10, 3, 3, 16, 32, 1, 1, 1, 9, true, 0>(a, s); break;     // P-Net conv1+prelu+pool
+        case 1:  FR_REQUIRE(H >= 3 && W >= 3, "P2 input too small");
+                 rc = launch_dc<10, 16, 3, 3, 8, 32, 1, 1, 1, 9, false, 0>(a, s); break;    // P-Net conv2
+        case 2:  FR_REQUIRE(H >= 3 && W >= 3 && head_w && head_b, "P3 needs head weights");
+                 rc = launch_dc<16, 32, 3, 3, 8, 32, 1, 2, 1, 9, false, 6>(a, s); break;    // P-Net conv3 + heads
+        case 10: FR_REQUIRE(H == 24 && W == 24, "R1 expects 24x24");
+                 rc = launch_dc<3, 28, 3, 3, 22, 22, 1, 2, 1, 9, false, 0>(a, s); break;
+        case 11: FR_REQUIRE(H == 11 && W == 11, "R2 expects 11x11");
+                 rc = launch_dc<28, 48, 3, 3, 9, 9, 2, 3, 1, 3, false, 0>(a, s); break;
+        case 12: FR_REQUIRE(H == 4 && W == 4, "R3 expects 4x4");
+                 rc = launch_dc<48, 64, 2, 2, 3, 3, 8, 4, 2, 1, false, 0>(a, s); break;
+        case 13: FR_REQUIRE(H == 3 && W == 3, "R4 expects 3x3");
+                 rc = launch_dc<64, 128, 3, 3, 1, 1, 16, 4, 4, 1, false, 0>(a, s); break;   // dense4
+        case 14: FR_REQUIRE(H == 1 && W == 1, "R5 expects 1x1");
+                 rc = launch_dc<128, 6, 1, 1, 1, 1, 64, 1, 1, 1, false, 0>(a, s); break;    // dense5_1|5_2
+        case 20: FR_REQUIRE(H == 48 && W == 48, "O1 expects 48x48");
+                 rc = launch_dc<3, 32, 3, 3, 8, 46, 1, 2, 1, 9, false, 0>(a, s); break;
+        case 21: FR_REQUIRE(H == 23 && W == 23, "O2 expects 23x23");
+                 rc = launch_dc<32, 64, 3, 3, 7, 21, 1, 4, 1, 3, false, 0>(a, s); break;
+        case 22: FR_REQUIRE(H == 10 && W == 10, "O3 expects 10x10");
+                 rc = launch_dc<64, 64, 3, 3, 8, 8, 1, 4, 1, 1, false, 0>(a, s); break;
+        case 23: FR_REQUIRE(H == 4 && W == 4, "O4 expects 4x4");
+                 rc = launch_dc<64, 128, 2, 2, 3, 3, 8, 4, 2, 1, false, 0>(a, s); break;
+        case 24: FR_REQUIRE(H == 3 && W == 3, "O5 expects 3x3");
+                 rc = launch_dc<128, 256, 3, 3, 1, 1, 16, 4, 4, 1, false, 0>(a, s); break;  // dense5
+        case 25: FR_REQUIRE(H == 1 && W == 1, "O6 expects 1x1");
+                 rc = launch_dc<256, 16, 1, 1, 1, 1, 64, 1, 1, 1, false, 0>(a, s); break;   // dense6_1|6_2|6_3
+        default: FR_REQUIRE(false, "fr_dconv_mfma_f32: unknown layer id %d", layer);
+    }
+    if (rc != FR_OK) return rc;
+    FR_CHECK_LAUNCH("dconv_mfma");
+    return FR_OK;
+}

@@ -59,6 +59,51 @@ class _DConv:
         return ((hc + 1) // 2, (wc + 1) // 2) if self.pool2 else (hc, wc)
 
 
+# layer id -> (cin, cout, kh, kw, ntb): must mirror the table in csrc/dconv_mfma.hip
+MFMA_LAYERS = {0: (3, 10, 3, 3, 1), 1: (10, 16, 3, 3, 1), 2: (16, 32, 3, 3, 2),
+               10: (3, 28, 3, 3, 2), 11: (28, 48, 3, 3, 3), 12: (48, 64, 2, 2, 4), 13: (64, 128, 3, 3, 4),
+               14: (128, 6, 1, 1, 1),
+               20: (3, 32, 3, 3, 2), 21: (32, 64, 3, 3, 4), 22: (64, 64, 3, 3, 4), 23: (64, 128, 2, 2, 4),
+               24: (128, 256, 3, 3, 4), 25: (256, 16, 1, 1, 1)}
+
+
+class _MConv:
+    """Detector layer packed for fr_dconv_mfma_f32: w [cout_group][tap][CinP][CP] f32 where
+    CinP = Cin rounded up to 4 and CP = NTB*16 (+16 when NTB is even: LDS bank spread)."""
+
+    def __init__(self, layer, w, b, slope, device, head=None):
+        cin, cout, kh, kw, ntb = MFMA_LAYERS[layer]
+        assert tuple(w.shape) == (cout, cin, kh, kw), (layer, tuple(w.shape))
+        self.layer, self.cin, self.cout, self.kh, self.kw = layer, cin, cout, kh, kw
+        cinp = -(-cin // 4) * 4
+        cp = ntb * 16 + (16 if ntb % 2 == 0 else 0)
+        gsz = ntb * 16
+        ngroups = -(-cout // gsz)
+        wp = torch.zeros((ngroups, kh * kw, cinp, cp), dtype=torch.float32)
+        wt = w.permute(2, 3, 1, 0).reshape(kh * kw, cin, cout)              # [tap][ci][co]
+        for g in range(ngroups):
+            n = min(gsz, cout - g * gsz)
+            wp[g, :, :cin, :n] = wt[:, :, g * gsz:g * gsz + n]
+        self.w = wp.contiguous().to(device)
+        bp = torch.zeros(ngroups * gsz); bp[:cout] = b
+        self.b = bp.to(device)
+        self.slope = None
+        if slope is not None:
+            sp = torch.zeros(ngroups * gsz); sp[:cout] = slope
+            self.slope = sp.to(device)
+        self.head_w = self.head_b = None
+        self.nhead = 0
+        if head is not None:
+            self.head_w = head[0].t().contiguous().to(torch.float32).to(device)      # [cout][nh]
+            self.head_b = head[1].to(torch.float32).contiguous().to(device)
+            self.nhead = head[0].shape[0]
+        self.pool2 = layer == 0
+
+    def out_hw(self, h, w):
+        hc, wc = h - self.kh + 1, w - self.kw + 1
+        return ((hc + 1) // 2, (wc + 1) // 2) if self.pool2 else (hc, wc)
+
+
 def _dense_as_conv(w, k, c):
     """MTCNN dense layer over a k x k x c map flattened (w, h, c) -> conv weight [o, c, kh, kw]."""
     o = w.shape[0]
@@ -76,23 +121,23 @@ class MTCNNHIP:
         assert cap_scale <= 4096 and cap_p <= 1024 and cap_r <= 1024 and cap_o <= 1024
         d = self.device
         p, r, o = ({k: v.detach().float().cpu() for k, v in s.items()} for s in (pstate, rstate, ostate))
-        self.p1 = _DConv(p["conv1.weight"], p["conv1.bias"], p["prelu1.weight"], d, pool2=True)
-        self.p2 = _DConv(p["conv2.weight"], p["conv2.bias"], p["prelu2.weight"], d)
+        self.p1 = _MConv(0, p["conv1.weight"], p["conv1.bias"], p["prelu1.weight"], d)
+        self.p2 = _MConv(1, p["conv2.weight"], p["conv2.bias"], p["prelu2.weight"], d)
         hw = torch.cat([p["conv4_1.weight"].reshape(2, 32), p["conv4_2.weight"].reshape(4, 32)])
         hb = torch.cat([p["conv4_1.bias"], p["conv4_2.bias"]])
-        self.p3 = _DConv(p["conv3.weight"], p["conv3.bias"], p["prelu3.weight"], d, head=(hw, hb))
-        self.r1 = _DConv(r["conv1.weight"], r["conv1.bias"], r["prelu1.weight"], d)
-        self.r2 = _DConv(r["conv2.weight"], r["conv2.bias"], r["prelu2.weight"], d)
-        self.r3 = _DConv(r["conv3.weight"], r["conv3.bias"], r["prelu3.weight"], d)
-        self.r4 = _DConv(_dense_as_conv(r["dense4.weight"], 3, 64), r["dense4.bias"], r["prelu4.weight"], d)
-        self.r5 = _DConv(torch.cat([r["dense5_1.weight"], r["dense5_2.weight"]]).reshape(6, 128, 1, 1),
+        self.p3 = _MConv(2, p["conv3.weight"], p["conv3.bias"], p["prelu3.weight"], d, head=(hw, hb))
+        self.r1 = _MConv(10, r["conv1.weight"], r["conv1.bias"], r["prelu1.weight"], d)
+        self.r2 = _MConv(11, r["conv2.weight"], r["conv2.bias"], r["prelu2.weight"], d)
+        self.r3 = _MConv(12, r["conv3.weight"], r["conv3.bias"], r["prelu3.weight"], d)
+        self.r4 = _MConv(13, _dense_as_conv(r["dense4.weight"], 3, 64), r["dense4.bias"], r["prelu4.weight"], d)
+        self.r5 = _MConv(14, torch.cat([r["dense5_1.weight"], r["dense5_2.weight"]]).reshape(6, 128, 1, 1),
                          torch.cat([r["dense5_1.bias"], r["dense5_2.bias"]]), None, d)
-        self.o1 = _DConv(o["conv1.weight"], o["conv1.bias"], o["prelu1.weight"], d)
-        self.o2 = _DConv(o["conv2.weight"], o["conv2.bias"], o["prelu2.weight"], d)
-        self.o3 = _DConv(o["conv3.weight"], o["conv3.bias"], o["prelu3.weight"], d)
-        self.o4 = _DConv(o["conv4.weight"], o["conv4.bias"], o["prelu4.weight"], d)
-        self.o5 = _DConv(_dense_as_conv(o["dense5.weight"], 3, 128), o["dense5.bias"], o["prelu5.weight"], d)
-        self.o6 = _DConv(torch.cat([o["dense6_1.weight"], o["dense6_2.weight"], o["dense6_3.weight"]]).reshape(16, 256, 1, 1),
+        self.o1 = _MConv(20, o["conv1.weight"], o["conv1.bias"], o["prelu1.weight"], d)
+        self.o2 = _MConv(21, o["conv2.weight"], o["conv2.bias"], o["prelu2.weight"], d)
+        self.o3 = _MConv(22, o["conv3.weight"], o["conv3.bias"], o["prelu3.weight"], d)
+        self.o4 = _MConv(23, o["conv4.weight"], o["conv4.bias"], o["prelu4.weight"], d)
+        self.o5 = _MConv(24, _dense_as_conv(o["dense5.weight"], 3, 128), o["dense5.bias"], o["prelu5.weight"], d)
+        self.o6 = _MConv(25, torch.cat([o["dense6_1.weight"], o["dense6_2.weight"], o["dense6_3.weight"]]).reshape(16, 256, 1, 1),
                          torch.cat([o["dense6_1.bias"], o["dense6_2.bias"], o["dense6_3.bias"]]), None, d)
 
     # ---- thin launch helpers (all on the current stream)
@@ -105,9 +150,13 @@ class MTCNNHIP:
     def _dconv(self, x, c, B, H, W):
         ho, wo = c.out_hw(H, W)
         y = self._f32(B, ho, wo, c.nhead if c.nhead else c.cout)
-        self.lib.fr_dconv_f32(_lib.ptr(x), _lib.ptr(c.w), _lib.ptr(c.b), _lib.ptr(c.slope), _lib.ptr(y), B, H, W,
-                              c.cin, c.cout, c.coutp, c.kh, c.kw, 1 if c.pool2 else 0, _lib.ptr(c.head_w),
-                              _lib.ptr(c.head_b), c.nhead, self._s)
+        if isinstance(c, _MConv):
+            self.lib.fr_dconv_mfma_f32(c.layer, _lib.ptr(x), _lib.ptr(c.w), _lib.ptr(c.b), _lib.ptr(c.slope), _lib.ptr(y),
+                                       B, H, W, _lib.ptr(c.head_w), _lib.ptr(c.head_b), self._s)
+        else:
+            self.lib.fr_dconv_f32(_lib.ptr(x), _lib.ptr(c.w), _lib.ptr(c.b), _lib.ptr(c.slope), _lib.ptr(y), B, H, W,
+                                  c.cin, c.cout, c.coutp, c.kh, c.kw, 1 if c.pool2 else 0, _lib.ptr(c.head_w),
+                                  _lib.ptr(c.head_b), c.nhead, self._s)
         return y, ho, wo
 
     def _pool(self, x, B, H, W, C, k, s):
