@@ -1,0 +1,133 @@
+"""GPU end-to-end parity through the reference-shaped API: FaceAnalysis.get + gallery match vs the
+full CPU oracle (detect -> align -> embed -> match) on the same inputs.
+north_star bar: embeddings within 1e-3 cosine, identical top-1 ids."""
+import os
+import sys
+import warnings
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import align as oalign, detect as odetect, match as omatch, nets as onets
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+
+
+@pytest.fixture(scope="module")
+def app():
+    from facerecognition_infrenceengine_amd import FaceAnalysis
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = FaceAnalysis(name="buffalo_l", providers=["CUDAExecutionProvider", "CPUExecutionProvider"])
+        a.prepare(ctx_id=0)
+    assert a.synthetic
+    return a
+
+
+def oracle_pipeline(frame):
+    from facerecognition_infrenceengine_amd import weights
+    p, r, o = weights.synth_mtcnn_states()
+    st = weights.synth_iresnet_state("r100")
+    b, s, k = odetect.detect(frame, p, r, o)
+    if len(s) == 0:
+        return b, s, k, np.zeros((0, 512), np.float32)
+    crops = [oalign.norm_crop(frame, kk)[0] for kk in k]
+    x = torch.from_numpy(np.stack([oalign.crop_to_net(c) for c in crops]))
+    emb = onets.iresnet_forward(st, x, weights.IRESNET_LAYERS["r100"]).numpy()
+    return b, s, k, emb
+
+
+@pytest.mark.parametrize("hw,seed", [((480, 640), 0), ((240, 320), 4)])
+def test_get_matches_oracle_pipeline(app, hw, seed):
+    """C1 of BASELINE.json: single 640x480 frame, detect+embed+match vs a 100-row gallery."""
+    from make_golden import synth_frame
+    from facerecognition_infrenceengine_amd import GalleryMatcher
+    frame = synth_frame(hw[0], hw[1], seed)
+    ob, os_, ok, oemb = oracle_pipeline(frame)
+    faces = app.get(frame)
+    assert len(faces) == len(os_) and len(faces) >= 1
+    emb = np.stack([f.embedding for f in faces]); normed = np.stack([f.normed_embedding for f in faces])
+    np.testing.assert_allclose(np.stack([f.bbox for f in faces]), ob, atol=5e-3)
+    np.testing.assert_allclose(np.stack([f.kps for f in faces]), ok, atol=5e-3)
+    np.testing.assert_allclose([f.det_score for f in faces], os_, atol=5e-5)
+    cos = (emb * oemb).sum(1) / (np.linalg.norm(emb, axis=1) * np.linalg.norm(oemb, axis=1))
+    assert (1 - cos).max() < 1e-3, cos
+    assert faces[0].bbox.dtype == np.float32 and faces[0].kps.shape == (5, 2) and normed.dtype == np.float32
+    # 100-row gallery with rows planted from the ORACLE embeddings (+ noise), rest random
+    rng = np.random.default_rng(1)
+    G = rng.standard_normal((100, 512)).astype(np.float32)
+    on = oemb / np.linalg.norm(oemb, axis=1, keepdims=True)
+    rows = rng.permutation(100)[:len(on)]
+    for f, r in enumerate(rows[: max(1, len(on) - 1)]):           # leave the last face unplanted (-> unknown)
+        G[r] = on[f] + 0.02 * rng.standard_normal(512)
+    G /= np.linalg.norm(G, axis=1, keepdims=True)
+    gal = OrderedDict((i, G[i]) for i in range(100))
+    want = []
+    for f in range(len(on)):                                      # literal reference loop on the oracle rows
+        bid, bs = omatch.linear_scan(omatch.renormalise(on[f].astype(np.float32)), gal)
+        want.append(bid if bs >= 0.4 else -1)
+    m = GalleryMatcher("cuda:0")
+    m.set_rows(list(range(100)), G, normalise=False)
+    ids, score, idx = m.match(normed, thr=0.4)
+    got = [-1 if i is None else i for i in ids]
+    assert got == want                                            # identical top-1 ids / unknown decisions
+
+
+def test_processor_end_to_end(app):
+    from make_golden import synth_frame
+    from facerecognition_infrenceengine_amd.processor import (CameraProcessor, EmbeddingManager,
+                                                              FaceRecognitionProcessor, InMemoryStore)
+    frame = synth_frame(240, 320, 4)
+    faces = app.get(frame)
+    store = InMemoryStore()
+    rng = np.random.default_rng(3)
+    for i in range(30):
+        store.add_employee(f"e{i}", "acme", rng.standard_normal(512), name=f"E{i}")
+    # enrol face 0 as a (mean-of-poses, un-normalised) row, as trainingServer.py:355 stores it
+    poses = [faces[0].normed_embedding + 0.01 * rng.standard_normal(512).astype(np.float32) for _ in range(3)]
+    store.add_employee("target", "acme", np.mean(poses, axis=0), name="Target")
+    store.add_employee("other_co", "globex", faces[0].normed_embedding, name="Elsewhere")
+    mgr = EmbeddingManager(store=store)
+    proc = FaceRecognitionProcessor(mgr, face_detector=app)
+    res = proc.recognize(frame, "acme")
+    assert len(res) == len(faces)
+    assert res[0]["person_id"] == "target" and res[0]["recognition_score"] > 0.9
+    assert all(r["person_id"] in (None, "target") for r in res)
+    assert np.array_equal(res[0]["bbox"], faces[0].bbox.astype(int))
+    out = proc.recognize_faces(frame.copy(), "acme")
+    assert out.shape == frame.shape and (out != frame).any()        # boxes drawn
+    assert proc.recognize(frame, "nobody") is None                   # empty gallery short-circuit (:523-525)
+    bad = proc.recognize_faces(np.zeros((4, 4), np.uint8), "acme")   # errors are swallowed (:560-563)
+    assert bad.shape == (4, 4)
+
+    class Mgr:
+        def __init__(self): self.rec, self.unk = [], []
+        def process_detection(self, pid, info, cam, ts, score): self.rec.append((pid, score))
+        def process_unknown_detection(self, cam, ts, emb, bbox): self.unk.append((emb, bbox))
+    cm = Mgr()
+    stats = CameraProcessor(mgr, cm, face_detector=app).process_frame(frame, "cam0")
+    assert stats["faces"] == len(faces) and stats["recognized"] >= 1
+    assert cm.rec[0][0] in ("target", "other_co") and stats["recognized"] + stats["unknown"] <= stats["faces"]
+    for emb, bbox in cm.unk:
+        assert abs(np.linalg.norm(emb) - 1) < 1e-5 and len(bbox) == 4
+
+
+def test_get_is_thread_safe(app):
+    """One engine shared by 3 threads, as the enrolment worker does (trainingServer.py:115,227)."""
+    import threading
+    from make_golden import synth_frame
+    frames = [synth_frame(120, 160, s) for s in (1, 2, 3)]
+    ref = [app.get(f) for f in frames]
+    out = [None] * 3
+
+    def work(i):
+        out[i] = app.get(frames[i])
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    for a, b in zip(ref, out):
+        assert len(a) == len(b)
+        for fa, fb in zip(a, b):
+            assert np.array_equal(fa.embedding, fb.embedding)

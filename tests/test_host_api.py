@@ -1,0 +1,95 @@
+"""Host logic without a GPU: EmbeddingManager ingest/sync/eviction/views, HTTP surface."""
+import pickle
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from facerecognition_infrenceengine_amd.processor import EmbeddingManager, InMemoryStore
+from facerecognition_infrenceengine_amd.server import create_app
+from oracle import match as omatch
+
+
+def _store():
+    rng = np.random.default_rng(0)
+    s = InMemoryStore()
+    for i in range(5):
+        s.add_employee(f"e{i}", "c1" if i < 3 else "c2", rng.standard_normal(512) * 3, name=f"E{i}")
+    s.add_employee("e_black", "c1", rng.standard_normal(512), blacklisted=True)
+    s.add_visitor("v0", "c1", rng.standard_normal(512), name="V0")
+    s.add_visitor("v_pending", "c1", rng.standard_normal(512), status="queued")
+    return s
+
+
+def test_ingest_normalises_and_orders_rows():
+    s = _store()
+    m = EmbeddingManager(store=s)
+    assert list(m.embeddings) == ["e0", "e1", "e2", "e3", "e4", "v0"]        # employees then visitors
+    for _id, row in m.embeddings.items():
+        blob = (s.employee_blobs if _id.startswith("e") else s.visitor_blobs)[_id]
+        assert np.array_equal(row, omatch.gallery_row_load(blob))               # infrenceServer.py:270-271
+    emb, meta = m.get_embeddings_for_company("c1")
+    assert list(emb) == ["e0", "e1", "e2", "v0"] and meta["v0"]["type"] == "visitor"
+    st = m.get_stats()
+    assert st == {"total_embeddings": 6, "employees": 5, "visitors": 1, "last_sync": st["last_sync"],
+                  "initial_load_complete": True}
+
+
+def test_sync_picks_up_updates_and_evicts():
+    s = _store()
+    m = EmbeddingManager(store=s)
+    time.sleep(0.01)
+    s.add_employee("e_new", "c1", np.ones(512), name="New")
+    s.employees[1]["status"] = "inactive"                                     # e1 leaves
+    m.force_sync()
+    assert "e_new" in m.embeddings and "e1" not in m.embeddings
+    assert list(m.get_embeddings_for_company("c1")[0]) == ["e0", "e2", "e_new", "v0"]
+
+
+def test_requires_injected_store():
+    with pytest.raises(ValueError):
+        EmbeddingManager("mongodb://example", "db")
+
+
+def test_http_surface_matches_reference():
+    s = _store()
+    m = EmbeddingManager(store=s)
+    started, stopped = [], []
+
+    class Cam:
+        def start_cameras(self, sources, company_id): started.append((sources, company_id))
+        def stop_cameras(self): stopped.append(1)
+    c = create_app(m, Cam()).test_client()
+    r = c.get("/api/embeddings/stats")
+    assert r.status_code == 200 and set(r.json) == {"total_embeddings", "employees", "visitors", "last_sync",
+                                                    "initial_load_complete"}
+    assert r.headers["Access-Control-Allow-Origin"] == "*"
+    r = c.post("/api/embeddings/sync")
+    assert r.status_code == 200 and r.json == {"status": "success", "message": "Sync completed"}
+    r = c.post("/api/camera/start", json={"sources": [0]})
+    assert r.status_code == 400 and r.json == {"status": "error", "message": "Company ID required"}
+    r = c.post("/api/camera/start", json={"company_id": "c1"})
+    assert r.status_code == 200 and r.json == {"status": "success", "message": "Camera started"}
+    for _ in range(100):
+        if started:
+            break
+        time.sleep(0.01)
+    assert started == [([0], "c1")]
+    r = c.post("/api/camera/stop")
+    assert r.json == {"status": "success", "message": "Camera stopped"} and stopped == [1]
+    m.force_sync = lambda: (_ for _ in ()).throw(RuntimeError("db down"))
+    r = c.post("/api/embeddings/sync")
+    assert r.status_code == 500 and r.json == {"status": "error", "message": "db down"}
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from facerecognition_infrenceengine_amd import FaceAnalysis, GalleryMatcher
+    from facerecognition_infrenceengine_amd._lib import FrError
+    with pytest.raises(FrError):
+        FaceAnalysis(name="x").prepare(ctx_id=0)
+    with pytest.raises(FrError):
+        GalleryMatcher("cuda:0")
