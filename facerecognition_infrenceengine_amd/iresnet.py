@@ -131,7 +131,7 @@ class IResNetHIP:
             e0.record()
             self.lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
             e1.record()
-            variant = "conv_mfma_kernel<%d, %s>" % (2 if c.cout % 128 == 0 else 1, "true" if c.cin == 8 else "false")
+            variant = "conv_mfma_pipe<%d, %s>" % (2 if c.cout % 128 == 0 else 1, "true" if c.cin == 8 else "false")
             kreal = 27 if c.cin == 8 else c.k * c.k * c.cin       # algorithmic K (stem: 3 real channels)
             self.profile.append((variant, 2.0 * B * Ho * Wo * c.cout * kreal, e0, e1))
         else:
