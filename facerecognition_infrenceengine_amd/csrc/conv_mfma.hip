@@ -398,11 +398,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pipe(ConvP p) {
 #endif
 }
 
-// Development A/B switch: FR_CONV_KERNEL = 2 (default) pipelined LDS-DMA ring, 1 = two-stage LDS-DMA,
-// 0 = two-stage register-staged loader.
+// Generic-path variant (layers the halo kernel does not take): FR_CONV_KERNEL = 1 (default) two-stage
+// LDS-DMA loader, K step 64; 2 = four-stage LDS-DMA ring, K step 32 (slower: a barrier per 16 MFMAs and ~100
+// cycles of issue per LDS-DMA piece outweigh the deeper prefetch); 0 = two-stage register-staged loader.
 static int conv_kernel_choice() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("FR_CONV_KERNEL"); v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }
+    if (v < 0) { const char* e = getenv("FR_CONV_KERNEL"); v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }
     return v;
 }
 

@@ -131,7 +131,13 @@ class IResNetHIP:
             e0.record()
             self.lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
             e1.record()
-            variant = "conv_mfma_pipe<%d, %s>" % (2 if c.cout % 128 == 0 else 1, "true" if c.cin == 8 else "false")
+            # mirror of the C dispatch (fr_conv_nhwc_f16): halo kernel for 3x3/s1 at 14x14 and 28x28
+            if c.k == 3 and c.stride == 1 and H == W and H in (14, 28) and c.cin % 64 == 0 and c.cout % 128 == 0 \
+                    and partial is None:
+                variant = "conv_halo_kernel<%d, false>" % (4 if c.cout % 256 == 0 else 2)
+            else:
+                variant = "conv_mfma_kernel<%d, %s, true>" % (2 if c.cout % 128 == 0 else 1,
+                                                             "true" if c.cin == 8 else "false")
             kreal = 27 if c.cin == 8 else c.k * c.k * c.cin       # algorithmic K (stem: 3 real channels)
             self.profile.append((variant, 2.0 * B * Ho * Wo * c.cout * kreal, e0, e1))
         else:
