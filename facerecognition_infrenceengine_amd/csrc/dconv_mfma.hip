@@ -20,12 +20,17 @@
 struct DcArgs {
     const float* x; const float* w; const float* bias; const float* slope; float* y;
     const float* head_w; const float* head_b;
-    int B, H, W;          // input images
+    int B, H, W;          // input images (for SRC == 1: the pyramid level size hs x ws)
     int Ho, Wo;           // conv output extent (H-KH+1, W-KW+1)
-    int regions_x;        // regions per image row
+    int regions_x, regions_y;
+    const uint8_t* frames; int FH, FW;   // SRC == 1: u8 BGR frames [B,FH,FW,3], resized on the fly
 };
 
-template <int CIN, int COUT, int KH, int KW, int RH, int RW, int G, int NTB, int WN, int TG, bool POOL2, int NHEAD>
+// POOL: 0 none | 1 fused 2x2/s2 ceil max pool in registers (needs RW % 16 == 0) | 2 fused PKxPK/s2 ceil max
+// pool through an LDS conv-output tile (regions step by RSY x RSX conv pixels, RH x RW computed per region).
+// RPB: regions per block along x (weights staged once per block).  SRC 1: input = bilinear resize of u8 frames.
+template <int CIN, int COUT, int KH, int KW, int RH, int RW, int G, int NTB, int WN, int TG, int POOL, int PK,
+          int RSY, int RSX, int NHEAD, int RPB, int SRC>
 struct DcCfg {
     static constexpr int CINP = (CIN + 3) / 4 * 4;
     static constexpr int CINS = CINP + 1;
@@ -38,37 +43,60 @@ struct DcCfg {
     static constexpr int NPIX = G * RH * RW;
     static constexpr int TP = (NPIX + 15) / 16;
     static constexpr int PT = (TP + WM - 1) / WM;
-    static constexpr int LDS_FLOATS = G * IMG + TG * CINP * CP;
+    static constexpr int CS = NTB * 16 + 1;                       // conv-output tile pixel stride (POOL == 2)
+    static constexpr int OUT_FLOATS = POOL == 2 ? NPIX * CS : 0;
+    static constexpr int IN_FLOATS = G * IMG > OUT_FLOATS ? G * IMG : OUT_FLOATS;   // the two tiles share LDS
+    static constexpr int W_OFF = (IN_FLOATS + 3) / 4 * 4;
+    static constexpr int LDS_FLOATS = W_OFF + TG * CINP * CP;
     static_assert(NTAPS % TG == 0, "TG must divide the tap count");
     static_assert(NTB % WN == 0 && (WN == 1 || WN == 2 || WN == 4), "bad wave split");
-    static_assert(!POOL2 || (RW % 16 == 0 && RH % 2 == 0 && G == 1 && WN == 1 && (RH * RW / 16) % 4 == 0), "pool layout");
+    static_assert(POOL != 1 || (RW % 16 == 0 && RH % 2 == 0 && G == 1 && WN == 1 && (RH * RW / 16) % 4 == 0), "pool layout");
+    static_assert(RPB == 1 || (G == 1 && NSTAGE == 1), "multi-region blocks need resident weights");
+    static_assert(SRC == 0 || CIN == 3, "fused resize feeds a 3-channel layer");
 };
 
-template <int CIN, int COUT, int KH, int KW, int RH, int RW, int G, int NTB, int WN, int TG, bool POOL2, int NHEAD>
+struct DLerp { int i0, i1; float w; };
+__device__ __forceinline__ DLerp dlerp_coord(int d, float ratio, int n) {      // == detect_ops.hip lerp_coord
+    float f = ((float)d + 0.5f) * ratio - 0.5f;
+    float fl = floorf(f);
+    DLerp r;
+    r.w = f - fl;
+    int i = (int)fl;
+    r.i0 = min(max(i, 0), n - 1);
+    r.i1 = min(max(i + 1, 0), n - 1);
+    return r;
+}
+__device__ __forceinline__ float dbilerp(float p00, float p01, float p10, float p11, float wx, float wy) {
+    float top = (1.0f - wx) * p00 + wx * p01;
+    float bot = (1.0f - wx) * p10 + wx * p11;
+    return (1.0f - wy) * top + wy * bot;
+}
+
+template <int CIN, int COUT, int KH, int KW, int RH, int RW, int G, int NTB, int WN, int TG, int POOL, int PK,
+          int RSY, int RSX, int NHEAD, int RPB, int SRC>
 __global__ __launch_bounds__(256) void dconv_mfma(DcArgs a) {
-    using C = DcCfg<CIN, COUT, KH, KW, RH, RW, G, NTB, WN, TG, POOL2, NHEAD>;
+    using C = DcCfg<CIN, COUT, KH, KW, RH, RW, G, NTB, WN, TG, POOL, PK, RSY, RSX, NHEAD, RPB, SRC>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xin = lds;
-    float* wl = lds + G * C::IMG;
+    float* wl = lds + C::W_OFF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave % WN, wm = wave / WN;
     const int li = lane & 15, kq = lane >> 4;
-    const int ry = blockIdx.x / a.regions_x, rx = blockIdx.x - ry * a.regions_x;
-    const int y0 = ry * RH, x0 = rx * RW;
+    const int gx = (a.regions_x + RPB - 1) / RPB;
+    const int ry = blockIdx.x / gx, bx = blockIdx.x - ry * gx;
+    const int y0 = ry * RSY;
     const int img0 = blockIdx.z * G;
     const int cg = blockIdx.y;
+    const float* wsrc = a.w + (int64_t)cg * C::NTAPS * C::CINP * C::CP;
 
-    // ---- stage the input tile (zero outside the image / beyond CIN)
-    for (int e = tid; e < G * C::IMG; e += 256) {
-        const int g = e / C::IMG, r = e - g * C::IMG;
-        const int pix = r / C::CINS, ci = r - pix * C::CINS;
-        const int iy = pix / C::IW, ix = pix - iy * C::IW;
-        const int n = img0 + g, yy = y0 + iy, xx = x0 + ix;
-        float v = 0.f;
-        if (ci < CIN && n < a.B && yy < a.H && xx < a.W) v = a.x[(((int64_t)n * a.H + yy) * a.W + xx) * CIN + ci];
-        xin[e] = v;
-    }
-    // ---- per-lane pixel bases
+    auto stage_weights = [&](int st) {
+        const float4v* src4 = reinterpret_cast<const float4v*>(wsrc + (int64_t)st * TG * C::CINP * C::CP);
+        float4v* dst4 = reinterpret_cast<float4v*>(wl);
+        for (int e = tid; e < TG * C::CINP * C::CP / 4; e += 256) dst4[e] = src4[e];
+    };
+    if (C::NSTAGE == 1) stage_weights(0);
+
+    // ---- per-lane pixel bases (region-relative, the same for every region of the block)
     int base[C::PT];
 #pragma unroll
     for (int t = 0; t < C::PT; ++t) {
@@ -81,167 +109,271 @@ __global__ __launch_bounds__(256) void dconv_mfma(DcArgs a) {
         }
         base[t] = b + kq;
     }
-    float4v acc[C::NT][C::PT];
-#pragma unroll
-    for (int i = 0; i < C::NT; ++i)
-#pragma unroll
-        for (int t = 0; t < C::PT; ++t) acc[i][t] = float4v{0.f, 0.f, 0.f, 0.f};
+    const int coW = (cg * NTB + wn * C::NT) * 16 + kq * 4;      // first cout of this lane in tile i: coW + i*16
 
-    const float* wsrc = a.w + (int64_t)cg * C::NTAPS * C::CINP * C::CP;
-    for (int st = 0; st < C::NSTAGE; ++st) {
-        if (st > 0) __syncthreads();
-        for (int e = tid; e < TG * C::CINP * C::CP; e += 256) wl[e] = wsrc[(int64_t)st * TG * C::CINP * C::CP + e];
-        __syncthreads();
+    for (int rr = 0; rr < RPB; ++rr) {
+        const int rx = bx * RPB + rr;
+        if (rx >= a.regions_x) break;
+        const int x0 = rx * RSX;
+        if (rr > 0) __syncthreads();                     // previous region's readers are done with the tiles
+
+        // ---- stage the input tile (zero outside the image / beyond CIN)
+        if constexpr (SRC == 1) {
+            const float ryr = (float)a.FH / (float)a.H, rxr = (float)a.FW / (float)a.W;
+            for (int e = tid; e < C::IH * C::IW; e += 256) {
+                const int iy = e / C::IW, ix = e - iy * C::IW;
+                const int n = img0, yy = y0 + iy, xx = x0 + ix;
+                float v[3] = {0.f, 0.f, 0.f};
+                if (n < a.B && yy < a.H && xx < a.W) {
+                    const DLerp ly = dlerp_coord(yy, ryr, a.FH), lx = dlerp_coord(xx, rxr, a.FW);
+                    const uint8_t* f = a.frames + (int64_t)n * a.FH * a.FW * 3;
+                    const uint8_t* r0 = f + (int64_t)ly.i0 * a.FW * 3;
+                    const uint8_t* r1 = f + (int64_t)ly.i1 * a.FW * 3;
 #pragma unroll
-        for (int tl = 0; tl < TG; ++tl) {
-            const int tap = st * TG + tl;
-            const int kh = tap / KW, kw = tap - kh * KW;
-            const int toff = (kh * C::IW + kw) * C::CINS;
-            const float* wt = wl + (tl * C::CINP + kq) * C::CP + wn * C::NT * 16 + li;
+                    for (int c = 0; c < 3; ++c) {
+                        const int ci = 2 - c;                       // BGR -> RGB
+                        const float s = dbilerp((float)r0[lx.i0 * 3 + ci], (float)r0[lx.i1 * 3 + ci],
+                                                (float)r1[lx.i0 * 3 + ci], (float)r1[lx.i1 * 3 + ci], lx.w, ly.w);
+                        v[c] = (s - 127.5f) * 0.0078125f;
+                    }
+                }
+                float* d = xin + e * C::CINS;
+                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = 0.f;
+            }
+        } else if constexpr (CIN % 4 == 0) {
+            constexpr int C4 = C::CINP / 4;
+            for (int e = tid; e < G * C::IH * C::IW * C4; e += 256) {
+                const int c4 = e % C4, pix_g = e / C4;
+                const int g = pix_g / (C::IH * C::IW), pix = pix_g - g * (C::IH * C::IW);
+                const int iy = pix / C::IW, ix = pix - iy * C::IW;
+                const int n = img0 + g, yy = y0 + iy, xx = x0 + ix;
+                float4v v = {0.f, 0.f, 0.f, 0.f};
+                if (n < a.B && yy < a.H && xx < a.W)
+                    v = *reinterpret_cast<const float4v*>(a.x + (((int64_t)n * a.H + yy) * a.W + xx) * CIN + c4 * 4);
+                float* d = xin + g * C::IMG + pix * C::CINS + c4 * 4;
+                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+            }
+        } else {
+            for (int e = tid; e < G * C::IMG; e += 256) {
+                const int g = e / C::IMG, r = e - g * C::IMG;
+                const int pix = r / C::CINS, ci = r - pix * C::CINS;
+                const int iy = pix / C::IW, ix = pix - iy * C::IW;
+                const int n = img0 + g, yy = y0 + iy, xx = x0 + ix;
+                float v = 0.f;
+                if (ci < CIN && n < a.B && yy < a.H && xx < a.W) v = a.x[(((int64_t)n * a.H + yy) * a.W + xx) * CIN + ci];
+                xin[e] = v;
+            }
+        }
+
+        float4v acc[C::NT][C::PT];
 #pragma unroll
-            for (int c4 = 0; c4 < C::CINP / 4; ++c4) {
-                float av[C::NT], bv[C::PT];
+        for (int i = 0; i < C::NT; ++i)
 #pragma unroll
-                for (int i = 0; i < C::NT; ++i) av[i] = wt[c4 * 4 * C::CP + i * 16];
+            for (int t = 0; t < C::PT; ++t) acc[i][t] = float4v{0.f, 0.f, 0.f, 0.f};
+
+        for (int st = 0; st < C::NSTAGE; ++st) {
+            if (C::NSTAGE > 1) {
+                if (st > 0) __syncthreads();
+                stage_weights(st);
+            }
+            __syncthreads();
 #pragma unroll
-                for (int t = 0; t < C::PT; ++t) bv[t] = xin[base[t] + toff + c4 * 4];
+            for (int tl = 0; tl < TG; ++tl) {
+                const int tap = st * TG + tl;
+                const int kh = tap / KW, kw = tap - kh * KW;
+                const int toff = (kh * C::IW + kw) * C::CINS;
+                const float* wt = wl + (tl * C::CINP + kq) * C::CP + wn * C::NT * 16 + li;
+#pragma unroll
+                for (int c4 = 0; c4 < C::CINP / 4; ++c4) {
+                    float av[C::NT], bv[C::PT];
+#pragma unroll
+                    for (int i = 0; i < C::NT; ++i) av[i] = wt[c4 * 4 * C::CP + i * 16];
+#pragma unroll
+                    for (int t = 0; t < C::PT; ++t) bv[t] = xin[base[t] + toff + c4 * 4];
+#pragma unroll
+                    for (int i = 0; i < C::NT; ++i)
+#pragma unroll
+                        for (int t = 0; t < C::PT; ++t)
+                            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[t], acc[i][t], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- epilogue: bias + PReLU
+#pragma unroll
+        for (int i = 0; i < C::NT; ++i) {
+            const float4v bv = *reinterpret_cast<const float4v*>(a.bias + coW + i * 16);
+            float4v sv = {1.f, 1.f, 1.f, 1.f};
+            if (a.slope) sv = *reinterpret_cast<const float4v*>(a.slope + coW + i * 16);
+#pragma unroll
+            for (int t = 0; t < C::PT; ++t) {
+                float4v v = acc[i][t] + bv;
+                if (a.slope) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * sv[e];
+                }
+                acc[i][t] = v;
+            }
+        }
+
+        if constexpr (POOL == 1) {
+            // tiles: t = TR*row_in_wave + half; pool rows (2a, 2a+1) in registers, lanes (2b, 2b+1) by one shuffle
+            constexpr int TR = RW / 16;
+            const int Hp = (a.Ho + 1) / 2, Wp = (a.Wo + 1) / 2;
+#pragma unroll
+            for (int i = 0; i < C::NT; ++i) {
+#pragma unroll
+                for (int t = 0; t < C::PT; ++t) {
+                    const int tile = wm * C::PT + t;
+                    const int ty = tile / TR, tx = (tile - ty * TR) * 16 + li;
+                    if (y0 + ty >= a.Ho || x0 + tx >= a.Wo) acc[i][t] = float4v{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                }
+                constexpr int ROWS = C::PT / TR;
+                static_assert(POOL != 1 || ROWS % 2 == 0, "a wave must own whole row pairs");
+#pragma unroll
+                for (int rp = 0; rp < ROWS / 2; ++rp) {
+#pragma unroll
+                    for (int hf = 0; hf < TR; ++hf) {
+                        const int t = 2 * rp * TR + hf;
+                        float4v v = acc[i][t];
+                        const float4v u = acc[i][t + TR];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float m = fmaxf(v[e], u[e]);
+                            float o = __shfl_xor(m, 1, 64);
+                            v[e] = fmaxf(m, o);
+                        }
+                        const int ty = wm * ROWS + 2 * rp;
+                        const int tx = hf * 16 + li;
+                        const int py = (y0 + ty) >> 1, px = (x0 + tx) >> 1;
+                        const int n = img0;
+                        if ((li & 1) == 0 && py < Hp && px < Wp && n < a.B) {
+                            float* o = a.y + (((int64_t)n * Hp + py) * Wp + px) * COUT;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (coW + i * 16 + e < COUT) o[coW + i * 16 + e] = v[e];
+                        }
+                    }
+                }
+            }
+        } else if constexpr (POOL == 2) {
+            // conv outputs -> LDS tile [pixel][CS] (shares the input tile's space), then PKxPK/s2 ceil max pool
+            __syncthreads();                               // every wave is done reading the input tile
+            float* ot = lds;
+#pragma unroll
+            for (int t = 0; t < C::PT; ++t) {
+                const int p = (wm * C::PT + t) * 16 + li;
+                if (p >= C::NPIX) continue;
+#pragma unroll
+                for (int i = 0; i < C::NT; ++i) {
+                    float* d = ot + p * C::CS + (wn * C::NT + i) * 16 + kq * 4;
+                    d[0] = acc[i][t][0]; d[1] = acc[i][t][1]; d[2] = acc[i][t][2]; d[3] = acc[i][t][3];
+                }
+            }
+            __syncthreads();
+            const int PH = (a.Ho - PK + 1) / 2 + 1 - ((((a.Ho - PK + 1) / 2) * 2 >= a.Ho) ? 1 : 0);
+            const int PW = (a.Wo - PK + 1) / 2 + 1 - ((((a.Wo - PK + 1) / 2) * 2 >= a.Wo) ? 1 : 0);
+            constexpr int PRH = RSY / 2, PRW = RSX / 2;     // pooled rows / cols owned by one region
+            constexpr int CG = NTB * 16;
+            for (int e = tid; e < G * PRH * PRW * CG; e += 256) {
+                const int co = e % CG, pp = e / CG;
+                const int g = pp / (PRH * PRW), q = pp - g * (PRH * PRW);
+                const int pyl = q / PRW, pxl = q - pyl * PRW;
+                const int py = y0 / 2 + pyl, px = x0 / 2 + pxl, n = img0 + g;
+                const int cout = cg * CG + co;
+                if (py >= PH || px >= PW || n >= a.B || cout >= COUT) continue;
+                float m = -INFINITY;
+#pragma unroll
+                for (int dy = 0; dy < PK; ++dy) {
+                    const int cy = 2 * pyl + dy;
+                    if (cy >= RH || y0 + cy >= a.Ho) continue;
+#pragma unroll
+                    for (int dx = 0; dx < PK; ++dx) {
+                        const int cx = 2 * pxl + dx;
+                        if (cx >= RW || x0 + cx >= a.Wo) continue;
+                        m = fmaxf(m, ot[(g * RH * RW + cy * RW + cx) * C::CS + co]);
+                    }
+                }
+                a.y[(((int64_t)n * PH + py) * PW + px) * COUT + cout] = m;
+            }
+        } else if constexpr (NHEAD > 0) {
+#pragma unroll
+            for (int t = 0; t < C::PT; ++t) {
+                float h[NHEAD > 0 ? NHEAD : 1];
+#pragma unroll
+                for (int k = 0; k < NHEAD; ++k) h[k] = 0.f;
 #pragma unroll
                 for (int i = 0; i < C::NT; ++i)
 #pragma unroll
-                    for (int t = 0; t < C::PT; ++t)
-                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[t], acc[i][t], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = coW + i * 16 + e;
+#pragma unroll
+                        for (int k = 0; k < NHEAD; ++k) h[k] = __builtin_fmaf(acc[i][t][e], a.head_w[c * NHEAD + k], h[k]);
+                    }
+#pragma unroll
+                for (int k = 0; k < NHEAD; ++k) {
+                    h[k] += __shfl_xor(h[k], 16, 64);
+                    h[k] += __shfl_xor(h[k], 32, 64);
+                    h[k] += a.head_b[k];
+                }
+                const int p = (wm * C::PT + t) * 16 + li;
+                if (kq == 0 && p < C::NPIX) {
+                    const int g = p / (RH * RW), q = p - g * (RH * RW);
+                    const int ty = q / RW, tx = q - ty * RW;
+                    const int n = img0 + g, oy = y0 + ty, ox = x0 + tx;
+                    if (n < a.B && oy < a.Ho && ox < a.Wo) {
+                        float* o = a.y + (((int64_t)n * a.Ho + oy) * a.Wo + ox) * NHEAD;
+#pragma unroll
+                        for (int k = 0; k < NHEAD; ++k) o[k] = h[k];
+                    }
+                }
             }
-        }
-    }
-
-    // ---- epilogue: bias + PReLU
-    const int coW = (cg * NTB + wn * C::NT) * 16 + kq * 4;      // first cout of this lane in tile i: coW + i*16
-#pragma unroll
-    for (int i = 0; i < C::NT; ++i) {
-        const float4v bv = *reinterpret_cast<const float4v*>(a.bias + coW + i * 16);
-        float4v sv = {1.f, 1.f, 1.f, 1.f};
-        if (a.slope) sv = *reinterpret_cast<const float4v*>(a.slope + coW + i * 16);
-#pragma unroll
-        for (int t = 0; t < C::PT; ++t) {
-            float4v v = acc[i][t] + bv;
-            if (a.slope) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * sv[e];
-            }
-            acc[i][t] = v;
-        }
-    }
-
-    if constexpr (POOL2) {
-        // tiles: t = 2*row_in_wave + half; wave owns rows wm*(PT/2) ..; pool rows (2a, 2a+1), lanes (2b, 2b+1)
-        constexpr int TR = RW / 16;                 // tiles per region row
-        const int Hp = (a.Ho + 1) / 2, Wp = (a.Wo + 1) / 2;
-#pragma unroll
-        for (int i = 0; i < C::NT; ++i) {
+        } else {
 #pragma unroll
             for (int t = 0; t < C::PT; ++t) {
-                const int tile = wm * C::PT + t;
-                const int ty = tile / TR, tx = (tile - ty * TR) * 16 + li;
-                if (y0 + ty >= a.Ho || x0 + tx >= a.Wo) acc[i][t] = float4v{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            }
-            constexpr int ROWS = C::PT / TR;            // region rows owned by this wave (even)
-            static_assert(ROWS % 2 == 0, "a wave must own whole row pairs");
-#pragma unroll
-            for (int rp = 0; rp < ROWS / 2; ++rp) {
-#pragma unroll
-                for (int hf = 0; hf < TR; ++hf) {
-                    const int t = 2 * rp * TR + hf;      // even row; partner row is tile t + TR
-                    float4v v = acc[i][t];
-                    const float4v u = acc[i][t + TR];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float m = fmaxf(v[e], u[e]);
-                        float o = __shfl_xor(m, 1, 64);
-                        v[e] = fmaxf(m, o);
-                    }
-                    const int ty = wm * ROWS + 2 * rp;
-                    const int tx = hf * 16 + li;
-                    const int py = (y0 + ty) >> 1, px = (x0 + tx) >> 1;
-                    const int n = img0;
-                    if ((li & 1) == 0 && py < Hp && px < Wp && n < a.B) {
-                        float* o = a.y + (((int64_t)n * Hp + py) * Wp + px) * COUT;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (coW + i * 16 + e < COUT) o[coW + i * 16 + e] = v[e];
-                    }
-                }
-            }
-        }
-    } else if constexpr (NHEAD > 0) {
-        // y[pixel][h] = head_b[h] + sum_c act[c] * head_w[c][h]; lane has 4*NT of the channels
-#pragma unroll
-        for (int t = 0; t < C::PT; ++t) {
-            float h[NHEAD];
-#pragma unroll
-            for (int k = 0; k < NHEAD; ++k) h[k] = 0.f;
-#pragma unroll
-            for (int i = 0; i < C::NT; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int c = coW + i * 16 + e;
-#pragma unroll
-                    for (int k = 0; k < NHEAD; ++k) h[k] = __builtin_fmaf(acc[i][t][e], a.head_w[c * NHEAD + k], h[k]);
-                }
-#pragma unroll
-            for (int k = 0; k < NHEAD; ++k) {
-                h[k] += __shfl_xor(h[k], 16, 64);
-                h[k] += __shfl_xor(h[k], 32, 64);
-                h[k] += a.head_b[k];
-            }
-            const int p = (wm * C::PT + t) * 16 + li;
-            if (kq == 0 && p < C::NPIX) {
+                const int p = (wm * C::PT + t) * 16 + li;
+                if (p >= C::NPIX) continue;
                 const int g = p / (RH * RW), q = p - g * (RH * RW);
                 const int ty = q / RW, tx = q - ty * RW;
                 const int n = img0 + g, oy = y0 + ty, ox = x0 + tx;
-                if (n < a.B && oy < a.Ho && ox < a.Wo) {
-                    float* o = a.y + (((int64_t)n * a.Ho + oy) * a.Wo + ox) * NHEAD;
+                if (n >= a.B || oy >= a.Ho || ox >= a.Wo) continue;
+                float* o = a.y + (((int64_t)n * a.Ho + oy) * a.Wo + ox) * COUT;
 #pragma unroll
-                    for (int k = 0; k < NHEAD; ++k) o[k] = h[k];
-                }
-            }
-        }
-    } else {
+                for (int i = 0; i < C::NT; ++i) {
+                    const int co = coW + i * 16;
+                    if constexpr (COUT % 4 == 0) {
+                        if (co < COUT) *reinterpret_cast<float4v*>(o + co) = acc[i][t];
+                    } else {
 #pragma unroll
-        for (int t = 0; t < C::PT; ++t) {
-            const int p = (wm * C::PT + t) * 16 + li;
-            if (p >= C::NPIX) continue;
-            const int g = p / (RH * RW), q = p - g * (RH * RW);
-            const int ty = q / RW, tx = q - ty * RW;
-            const int n = img0 + g, oy = y0 + ty, ox = x0 + tx;
-            if (n >= a.B || oy >= a.Ho || ox >= a.Wo) continue;
-            float* o = a.y + (((int64_t)n * a.Ho + oy) * a.Wo + ox) * COUT;
-#pragma unroll
-            for (int i = 0; i < C::NT; ++i) {
-                const int co = coW + i * 16;
-                if constexpr (COUT % 4 == 0) {
-                    if (co < COUT) *reinterpret_cast<float4v*>(o + co) = acc[i][t];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (co + e < COUT) o[co + e] = acc[i][t][e];
+                        for (int e = 0; e < 4; ++e)
+                            if (co + e < COUT) o[co + e] = acc[i][t][e];
+                    }
                 }
             }
         }
     }
 }
 
-template <int CIN, int COUT, int KH, int KW, int RH, int RW, int G, int NTB, int WN, int TG, bool POOL2, int NHEAD>
+template <int CIN, int COUT, int KH, int KW, int RH, int RW, int G, int NTB, int WN, int TG, int POOL, int PK,
+          int RSY, int RSX, int NHEAD, int RPB, int SRC>
 static int launch_dc(const DcArgs& a0, hipStream_t s) {
-    using C = DcCfg<CIN, COUT, KH, KW, RH, RW, G, NTB, WN, TG, POOL2, NHEAD>;
+    using C = DcCfg<CIN, COUT, KH, KW, RH, RW, G, NTB, WN, TG, POOL, PK, RSY, RSX, NHEAD, RPB, SRC>;
     DcArgs a = a0;
     a.Ho = a.H - KH + 1; a.Wo = a.W - KW + 1;
-    a.regions_x = (a.Wo + RW - 1) / RW;
-    const int regions_y = (a.Ho + RH - 1) / RH;
+    if constexpr (POOL == 2) {      // regions tile the POOLED output: a region owns RSY/2 x RSX/2 pooled pixels
+        const int PH = (a.Ho - PK + 1) / 2 + 1 - ((((a.Ho - PK + 1) / 2) * 2 >= a.Ho) ? 1 : 0);
+        const int PW = (a.Wo - PK + 1) / 2 + 1 - ((((a.Wo - PK + 1) / 2) * 2 >= a.Wo) ? 1 : 0);
+        a.regions_x = (PW + RSX / 2 - 1) / (RSX / 2);
+        a.regions_y = (PH + RSY / 2 - 1) / (RSY / 2);
+    } else {
+        a.regions_x = (a.Wo + RSX - 1) / RSX;
+        a.regions_y = (a.Ho + RSY - 1) / RSY;
+    }
     constexpr int COUTP = (COUT + 15) / 16 * 16;
     static_assert(COUTP % (NTB * 16) == 0, "cout groups must tile COUTP");
-    dim3 grid(a.regions_x * regions_y, COUTP / (NTB * 16), (a.B + G - 1) / G);
+    dim3 grid(((a.regions_x + RPB - 1) / RPB) * a.regions_y, COUTP / (NTB * 16), (a.B + G - 1) / G);
     const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
-    auto kern = dconv_mfma<CIN, COUT, KH, KW, RH, RW, G, NTB, WN, TG, POOL2, NHEAD>;
+    auto kern = dconv_mfma<CIN, COUT, KH, KW, RH, RW, G, NTB, WN, TG, POOL, PK, RSY, RSX, NHEAD, RPB, SRC>;
     if (lds > 64 * 1024) {
         static bool done = false;       // attribute is per function; benign race (idempotent)
         if (!done) {
@@ -260,41 +392,44 @@ static int launch_dc(const DcArgs& a0, hipStream_t s) {
 // Layer table (see mtcnn.py: layer ids).  Geometry is fixed by the MTCNN architecture.
 extern "C" int fr_dconv_mfma_f32(int layer, const float* x, const float* w, const float* bias, const float* slope,
                                  float* y, int B, int H, int W, const float* head_w, const float* head_b,
-                                 fr_stream_t stream) {
-    FR_REQUIRE(x && w && bias && y && B > 0 && H > 0 && W > 0, "fr_dconv_mfma_f32: bad argument");
-    DcArgs a{x, w, bias, slope, y, head_w, head_b, B, H, W, 0, 0, 0};
+                                 const uint8_t* frames, int FH, int FW, fr_stream_t stream) {
+    FR_REQUIRE(w && bias && y && B > 0 && H > 0 && W > 0, "fr_dconv_mfma_f32: bad argument");
+    FR_REQUIRE(x || (layer == 0 && frames && FH > 0 && FW > 0), "fr_dconv_mfma_f32: no input");
+    DcArgs a{x, w, bias, slope, y, head_w, head_b, B, H, W, 0, 0, 0, 0, frames, FH, FW};
     hipStream_t s = fr_stream(stream);
     int rc = FR_OK;
     switch (layer) {
-        //                    CIN COUT KH KW RH  RW  G  NTB WN TG  POOL2  NHEAD
-        case 0:  FR_REQUIRE(H >= 3 && W >= 3, "P1 input too small");
-                 rc = launch_dc<3, 10, 3, 3, 16, 32, 1, 1, 1, 9, true, 0>(a, s); break;     // P-Net conv1+prelu+pool
+        //                  CIN COUT KH KW RH  RW  G NTB WN TG POOL PK RSY RSX NHEAD RPB SRC
+        case 0:  FR_REQUIRE(H >= 3 && W >= 3, "P1 input too small");                       // P-Net conv1+prelu+pool
+                 if (frames) rc = launch_dc<3, 10, 3, 3, 16, 32, 1, 1, 1, 9, 1, 2, 16, 32, 0, 4, 1>(a, s);
+                 else        rc = launch_dc<3, 10, 3, 3, 16, 32, 1, 1, 1, 9, 1, 2, 16, 32, 0, 4, 0>(a, s);
+                 break;
         case 1:  FR_REQUIRE(H >= 3 && W >= 3, "P2 input too small");
-                 rc = launch_dc<10, 16, 3, 3, 8, 32, 1, 1, 1, 9, false, 0>(a, s); break;    // P-Net conv2
+                 rc = launch_dc<10, 16, 3, 3, 8, 32, 1, 1, 1, 9, 0, 2, 8, 32, 0, 4, 0>(a, s); break;      // P-Net conv2
         case 2:  FR_REQUIRE(H >= 3 && W >= 3 && head_w && head_b, "P3 needs head weights");
-                 rc = launch_dc<16, 32, 3, 3, 8, 32, 1, 2, 1, 9, false, 6>(a, s); break;    // P-Net conv3 + heads
-        case 10: FR_REQUIRE(H == 24 && W == 24, "R1 expects 24x24");
-                 rc = launch_dc<3, 28, 3, 3, 22, 22, 1, 2, 1, 9, false, 0>(a, s); break;
-        case 11: FR_REQUIRE(H == 11 && W == 11, "R2 expects 11x11");
-                 rc = launch_dc<28, 48, 3, 3, 9, 9, 2, 3, 1, 3, false, 0>(a, s); break;
+                 rc = launch_dc<16, 32, 3, 3, 8, 32, 1, 2, 1, 9, 0, 2, 8, 32, 6, 4, 0>(a, s); break;      // P-Net conv3+heads
+        case 10: FR_REQUIRE(H == 24 && W == 24, "R1 expects 24x24");                        // conv1 + 3x3/s2 pool -> 11x11
+                 rc = launch_dc<3, 28, 3, 3, 22, 22, 1, 2, 1, 9, 2, 3, 22, 22, 0, 1, 0>(a, s); break;
+        case 11: FR_REQUIRE(H == 11 && W == 11, "R2 expects 11x11");                        // conv2 + 3x3/s2 pool -> 4x4
+                 rc = launch_dc<28, 48, 3, 3, 9, 9, 2, 3, 1, 3, 2, 3, 8, 8, 0, 1, 0>(a, s); break;
         case 12: FR_REQUIRE(H == 4 && W == 4, "R3 expects 4x4");
-                 rc = launch_dc<48, 64, 2, 2, 3, 3, 8, 4, 2, 1, false, 0>(a, s); break;
+                 rc = launch_dc<48, 64, 2, 2, 3, 3, 8, 4, 2, 1, 0, 2, 3, 3, 0, 1, 0>(a, s); break;
         case 13: FR_REQUIRE(H == 3 && W == 3, "R4 expects 3x3");
-                 rc = launch_dc<64, 128, 3, 3, 1, 1, 16, 4, 4, 1, false, 0>(a, s); break;   // dense4
+                 rc = launch_dc<64, 128, 3, 3, 1, 1, 16, 4, 4, 1, 0, 2, 1, 1, 0, 1, 0>(a, s); break;      // dense4
         case 14: FR_REQUIRE(H == 1 && W == 1, "R5 expects 1x1");
-                 rc = launch_dc<128, 6, 1, 1, 1, 1, 64, 1, 1, 1, false, 0>(a, s); break;    // dense5_1|5_2
-        case 20: FR_REQUIRE(H == 48 && W == 48, "O1 expects 48x48");
-                 rc = launch_dc<3, 32, 3, 3, 8, 46, 1, 2, 1, 9, false, 0>(a, s); break;
-        case 21: FR_REQUIRE(H == 23 && W == 23, "O2 expects 23x23");
-                 rc = launch_dc<32, 64, 3, 3, 7, 21, 1, 4, 1, 3, false, 0>(a, s); break;
-        case 22: FR_REQUIRE(H == 10 && W == 10, "O3 expects 10x10");
-                 rc = launch_dc<64, 64, 3, 3, 8, 8, 1, 4, 1, 1, false, 0>(a, s); break;
+                 rc = launch_dc<128, 6, 1, 1, 1, 1, 64, 1, 1, 1, 0, 2, 1, 1, 0, 1, 0>(a, s); break;       // dense5_1|5_2
+        case 20: FR_REQUIRE(H == 48 && W == 48, "O1 expects 48x48");                        // conv1 + 3x3/s2 pool -> 23x23
+                 rc = launch_dc<3, 32, 3, 3, 9, 46, 1, 2, 1, 9, 2, 3, 8, 46, 0, 1, 0>(a, s); break;
+        case 21: FR_REQUIRE(H == 23 && W == 23, "O2 expects 23x23");                        // conv2 + 3x3/s2 pool -> 10x10
+                 rc = launch_dc<32, 64, 3, 3, 7, 21, 1, 4, 1, 3, 2, 3, 6, 20, 0, 1, 0>(a, s); break;
+        case 22: FR_REQUIRE(H == 10 && W == 10, "O3 expects 10x10");                        // conv3 + 2x2/s2 pool -> 4x4
+                 rc = launch_dc<64, 64, 3, 3, 8, 8, 1, 4, 1, 1, 2, 2, 8, 8, 0, 1, 0>(a, s); break;
         case 23: FR_REQUIRE(H == 4 && W == 4, "O4 expects 4x4");
-                 rc = launch_dc<64, 128, 2, 2, 3, 3, 8, 4, 2, 1, false, 0>(a, s); break;
+                 rc = launch_dc<64, 128, 2, 2, 3, 3, 8, 4, 2, 1, 0, 2, 3, 3, 0, 1, 0>(a, s); break;
         case 24: FR_REQUIRE(H == 3 && W == 3, "O5 expects 3x3");
-                 rc = launch_dc<128, 256, 3, 3, 1, 1, 16, 4, 4, 1, false, 0>(a, s); break;  // dense5
+                 rc = launch_dc<128, 256, 3, 3, 1, 1, 16, 4, 4, 1, 0, 2, 1, 1, 0, 1, 0>(a, s); break;     // dense5
         case 25: FR_REQUIRE(H == 1 && W == 1, "O6 expects 1x1");
-                 rc = launch_dc<256, 16, 1, 1, 1, 1, 64, 1, 1, 1, false, 0>(a, s); break;   // dense6_1|6_2|6_3
+                 rc = launch_dc<256, 16, 1, 1, 1, 1, 64, 1, 1, 1, 0, 2, 1, 1, 0, 1, 0>(a, s); break;      // dense6_*
         default: FR_REQUIRE(false, "fr_dconv_mfma_f32: unknown layer id %d", layer);
     }
     if (rc != FR_OK) return rc;

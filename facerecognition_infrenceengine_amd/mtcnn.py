@@ -97,11 +97,11 @@ class _MConv:
             self.head_w = head[0].t().contiguous().to(torch.float32).to(device)      # [cout][nh]
             self.head_b = head[1].to(torch.float32).contiguous().to(device)
             self.nhead = head[0].shape[0]
-        self.pool2 = layer == 0
+        self.pool = {0: 2, 10: 3, 11: 3, 20: 3, 21: 3, 22: 2}.get(layer, 0)     # fused ceil-mode max pool, stride 2
 
     def out_hw(self, h, w):
         hc, wc = h - self.kh + 1, w - self.kw + 1
-        return ((hc + 1) // 2, (wc + 1) // 2) if self.pool2 else (hc, wc)
+        return (_pool_out(hc, self.pool, 2), _pool_out(wc, self.pool, 2)) if self.pool else (hc, wc)
 
 
 def _dense_as_conv(w, k, c):
@@ -147,12 +147,13 @@ class MTCNNHIP:
     def _i32(self, *shape):
         return torch.empty(shape, dtype=torch.int32, device=self.device)
 
-    def _dconv(self, x, c, B, H, W):
+    def _dconv(self, x, c, B, H, W, frames=None):
         ho, wo = c.out_hw(H, W)
         y = self._f32(B, ho, wo, c.nhead if c.nhead else c.cout)
         if isinstance(c, _MConv):
+            fh, fw = (frames.shape[1], frames.shape[2]) if frames is not None else (0, 0)
             self.lib.fr_dconv_mfma_f32(c.layer, _lib.ptr(x), _lib.ptr(c.w), _lib.ptr(c.b), _lib.ptr(c.slope), _lib.ptr(y),
-                                       B, H, W, _lib.ptr(c.head_w), _lib.ptr(c.head_b), self._s)
+                                       B, H, W, _lib.ptr(c.head_w), _lib.ptr(c.head_b), _lib.ptr(frames), fh, fw, self._s)
         else:
             self.lib.fr_dconv_f32(_lib.ptr(x), _lib.ptr(c.w), _lib.ptr(c.b), _lib.ptr(c.slope), _lib.ptr(y), B, H, W,
                                   c.cin, c.cout, c.coutp, c.kh, c.kw, 1 if c.pool2 else 0, _lib.ptr(c.head_w),
@@ -178,32 +179,24 @@ class MTCNNHIP:
         """frames u8 [N,H,W,3] -> head f32 [N,hc,wc,6] of one pyramid level."""
         N, H, W, _ = frames.shape
         hs, ws = int(math.ceil(H * scale)), int(math.ceil(W * scale))
-        img = self._f32(N, hs, ws, 3)
-        self.lib.fr_pyramid_resize_norm(_lib.ptr(frames), N, H, W, hs, ws, _lib.ptr(img), self._s)
-        x, h, w = self._dconv(img, self.p1, N, hs, ws)
+        # the pyramid level is resized inside P-Net conv1's tile load (no f32 level image in HBM)
+        x, h, w = self._dconv(None, self.p1, N, hs, ws, frames=frames)
         x, h, w = self._dconv(x, self.p2, N, h, w)
         head, h, w = self._dconv(x, self.p3, N, h, w)
-        if trace is not None:
-            trace.setdefault("pnet_img", []).append(img)
         return head, h, w
 
     def rnet(self, x, B):
-        x, h, w = self._dconv(x, self.r1, B, 24, 24)
-        x, h, w = self._pool(x, B, h, w, 28, 3, 2)
-        x, h, w = self._dconv(x, self.r2, B, h, w)
-        x, h, w = self._pool(x, B, h, w, 48, 3, 2)
+        x, h, w = self._dconv(x, self.r1, B, 24, 24)        # + fused 3x3/s2 pool -> 11x11
+        x, h, w = self._dconv(x, self.r2, B, h, w)          # + fused 3x3/s2 pool -> 4x4
         x, h, w = self._dconv(x, self.r3, B, h, w)
         x, h, w = self._dconv(x, self.r4, B, h, w)
         x, h, w = self._dconv(x, self.r5, B, 1, 1)
         return x.reshape(B, 6)
 
     def onet(self, x, B):
-        x, h, w = self._dconv(x, self.o1, B, 48, 48)
-        x, h, w = self._pool(x, B, h, w, 32, 3, 2)
-        x, h, w = self._dconv(x, self.o2, B, h, w)
-        x, h, w = self._pool(x, B, h, w, 64, 3, 2)
-        x, h, w = self._dconv(x, self.o3, B, h, w)
-        x, h, w = self._pool(x, B, h, w, 64, 2, 2)
+        x, h, w = self._dconv(x, self.o1, B, 48, 48)        # + fused 3x3/s2 pool -> 23x23
+        x, h, w = self._dconv(x, self.o2, B, h, w)          # + fused 3x3/s2 pool -> 10x10
+        x, h, w = self._dconv(x, self.o3, B, h, w)          # + fused 2x2/s2 pool -> 4x4
         x, h, w = self._dconv(x, self.o4, B, h, w)
         x, h, w = self._dconv(x, self.o5, B, h, w)
         x, h, w = self._dconv(x, self.o6, B, 1, 1)

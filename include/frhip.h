@@ -111,14 +111,17 @@ int fr_dconv_f32(const float* x, const float* w, const float* bias, const float*
                  int B, int H, int W, int Cin, int Cout, int CoutP, int KH, int KW, int pool2,
                  const float* head_w, const float* head_b, int nhead, fr_stream_t stream);
 /* MTCNN layers as LDS-tiled implicit GEMMs on v_mfma_f32_16x16x4_f32 (exact f32), the product path
- * of the detector.  `layer` selects a fixed geometry: 0/1/2 = P-Net conv1(+PReLU+2x2 pool) / conv2 /
- * conv3(+heads: y = [..,6]); 10..14 = R-Net conv1, conv2, conv3, dense4, dense5_1|5_2;
- * 20..25 = O-Net conv1..conv4, dense5, dense6_1|6_2|6_3.  x f32 NHWC [B,H,W,Cin];
- * w packed [cout_group][tap][CinP][CP] (mtcnn.py _MConv); bias/slope padded to the group size;
- * slope NULL = no PReLU.  Pooling layers 3x3/s2 stay in fr_maxpool_f32. */
+ * of the detector.  `layer` selects a fixed geometry, with the following max pool FUSED where the net has one:
+ * 0/1/2 = P-Net conv1(+PReLU+2x2 pool) / conv2 / conv3(+heads: y = [..,6]);
+ * 10..14 = R-Net conv1(+3x3/s2 pool), conv2(+3x3/s2 pool), conv3, dense4, dense5_1|5_2;
+ * 20..25 = O-Net conv1(+pool), conv2(+pool), conv3(+2x2 pool), conv4, dense5, dense6_1|6_2|6_3.
+ * x f32 NHWC [B,H,W,Cin]; w packed [cout_group][tap][CinP][CP] (mtcnn.py _MConv); bias/slope padded to
+ * the group size; slope NULL = no PReLU.  Layer 0 may instead take `frames` (u8 BGR [B,FH,FW,3]) with
+ * x == NULL: the pyramid level (H x W) is then resized on the fly inside the tile load, with the same
+ * arithmetic as fr_pyramid_resize_norm. */
 int fr_dconv_mfma_f32(int layer, const float* x, const float* w, const float* bias, const float* slope,
                       float* y, int B, int H, int W, const float* head_w, const float* head_b,
-                      fr_stream_t stream);
+                      const uint8_t* frames, int FH, int FW, fr_stream_t stream);
 /* max pool, ceil mode, f32 NHWC */
 int fr_maxpool_f32(const float* x, float* y, int B, int H, int W, int C, int k, int stride,
                    fr_stream_t stream);
