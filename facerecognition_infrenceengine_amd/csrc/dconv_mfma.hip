@@ -16,6 +16,7 @@
 // Optional fused epilogues: PReLU, 2x2/s2 ceil-mode max pool (P-Net conv1), 1x1 head (P-Net
 // conv3 -> 2 logits + 4 regressions).
 #include "common.h"
+#include <cstdlib>
 
 struct DcArgs {
     const float* x; const float* w; const float* bias; const float* slope; float* y;
@@ -24,6 +25,7 @@ struct DcArgs {
     int Ho, Wo;           // conv output extent (H-KH+1, W-KW+1)
     int regions_x, regions_y;
     const uint8_t* frames; int FH, FW;   // SRC == 1: u8 BGR frames [B,FH,FW,3], resized on the fly
+    int dbg;                             // development ablation (timing only): 1 = skip the MFMAs
 };
 
 // POOL: 0 none | 1 fused 2x2/s2 ceil max pool in registers (needs RW % 16 == 0) | 2 fused PKxPK/s2 ceil max
@@ -51,7 +53,8 @@ struct DcCfg {
     static_assert(NTAPS % TG == 0, "TG must divide the tap count");
     static_assert(NTB % WN == 0 && (WN == 1 || WN == 2 || WN == 4), "bad wave split");
     static_assert(POOL != 1 || (RW % 16 == 0 && RH % 2 == 0 && G == 1 && WN == 1 && (RH * RW / 16) % 4 == 0), "pool layout");
-    static_assert(RPB == 1 || (G == 1 && NSTAGE == 1), "multi-region blocks need resident weights");
+    static_assert(RPB == 1 || NSTAGE == 1, "multi-item blocks need resident weights");
+    static_assert(CIN % 4 == 0 || SRC == 1, "f32 inputs are read as float4: pad channels to a multiple of 4");
     static_assert(SRC == 0 || CIN == 3, "fused resize feeds a 3-channel layer");
 };
 
@@ -82,21 +85,83 @@ __global__ __launch_bounds__(256) void dconv_mfma(DcArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave % WN, wm = wave / WN;
     const int li = lane & 15, kq = lane >> 4;
-    const int gx = (a.regions_x + RPB - 1) / RPB;
-    const int ry = blockIdx.x / gx, bx = blockIdx.x - ry * gx;
-    const int y0 = ry * RSY;
-    const int img0 = blockIdx.z * G;
     const int cg = blockIdx.y;
     const float* wsrc = a.w + (int64_t)cg * C::NTAPS * C::CINP * C::CP;
+    // work items = (image group, region row, region col), RPB consecutive items per block
+    const int per_img = a.regions_x * a.regions_y;
+    const int nitems = per_img * ((a.B + G - 1) / G);
+    const int item0 = blockIdx.x * RPB;
 
     auto stage_weights = [&](int st) {
         const float4v* src4 = reinterpret_cast<const float4v*>(wsrc + (int64_t)st * TG * C::CINP * C::CP);
         float4v* dst4 = reinterpret_cast<float4v*>(wl);
         for (int e = tid; e < TG * C::CINP * C::CP / 4; e += 256) dst4[e] = src4[e];
     };
+
+    // ---- input tile: global -> registers (issued early, lands under the previous item's MFMAs) -> LDS
+    constexpr int C4 = C::CINP / 4;
+    constexpr int NLOAD = SRC == 1 ? C::IH * C::IW : G * C::IH * C::IW * C4;     // float4 slots of one tile
+    constexpr int NPF = (NLOAD + 255) / 256;
+    float4v pf[NPF];
+    auto load_tile = [&](int item) {
+        const int zz = item / per_img, rem = item - zz * per_img;
+        const int ry = rem / a.regions_x, rx = rem - ry * a.regions_x;
+        const int y0 = ry * RSY, x0 = rx * RSX, img0 = zz * G;
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int e = tid + u * 256;
+            float4v v = {0.f, 0.f, 0.f, 0.f};
+            if (e < NLOAD) {
+                if constexpr (SRC == 1) {
+                    const int iy = e / C::IW, ix = e - iy * C::IW;
+                    const int n = img0, yy = y0 + iy, xx = x0 + ix;
+                    if (n < a.B && yy < a.H && xx < a.W) {
+                        const float ryr = (float)a.FH / (float)a.H, rxr = (float)a.FW / (float)a.W;
+                        const DLerp ly = dlerp_coord(yy, ryr, a.FH), lx = dlerp_coord(xx, rxr, a.FW);
+                        const uint8_t* f = a.frames + (int64_t)n * a.FH * a.FW * 3;
+                        const uint8_t* r0 = f + (int64_t)ly.i0 * a.FW * 3;
+                        const uint8_t* r1 = f + (int64_t)ly.i1 * a.FW * 3;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const int ci = 2 - c;                   // BGR -> RGB
+                            const float sv = dbilerp((float)r0[lx.i0 * 3 + ci], (float)r0[lx.i1 * 3 + ci],
+                                                     (float)r1[lx.i0 * 3 + ci], (float)r1[lx.i1 * 3 + ci], lx.w, ly.w);
+                            v[c] = (sv - 127.5f) * 0.0078125f;
+                        }
+                    }
+                } else {
+                    const int c4 = e % C4, pix_g = e / C4;
+                    const int g = pix_g / (C::IH * C::IW), pix = pix_g - g * (C::IH * C::IW);
+                    const int iy = pix / C::IW, ix = pix - iy * C::IW;
+                    const int n = img0 + g, yy = y0 + iy, xx = x0 + ix;
+                    if (n < a.B && yy < a.H && xx < a.W)
+                        v = *reinterpret_cast<const float4v*>(a.x + (((int64_t)n * a.H + yy) * a.W + xx) * CIN + c4 * 4);
+                }
+            }
+            pf[u] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int e = tid + u * 256;
+            if (e < NLOAD) {
+                float* d;
+                if constexpr (SRC == 1) d = xin + e * C::CINS;
+                else {
+                    const int c4 = e % C4, pix_g = e / C4;
+                    const int g = pix_g / (C::IH * C::IW), pix = pix_g - g * (C::IH * C::IW);
+                    d = xin + g * C::IMG + pix * C::CINS + c4 * 4;
+                }
+                d[0] = pf[u][0]; d[1] = pf[u][1]; d[2] = pf[u][2]; d[3] = pf[u][3];
+            }
+        }
+    };
+
+    if (item0 < nitems) load_tile(item0);
     if (C::NSTAGE == 1) stage_weights(0);
 
-    // ---- per-lane pixel bases (region-relative, the same for every region of the block)
+    // ---- per-lane pixel bases (region-relative, the same for every item)
     int base[C::PT];
 #pragma unroll
     for (int t = 0; t < C::PT; ++t) {
@@ -110,60 +175,32 @@ __global__ __launch_bounds__(256) void dconv_mfma(DcArgs a) {
         base[t] = b + kq;
     }
     const int coW = (cg * NTB + wn * C::NT) * 16 + kq * 4;      // first cout of this lane in tile i: coW + i*16
+    // bias / PReLU slopes / head weights of this lane's channels: loaded once per block
+    float4v bias_r[C::NT], slope_r[C::NT];
+#pragma unroll
+    for (int i = 0; i < C::NT; ++i) {
+        bias_r[i] = *reinterpret_cast<const float4v*>(a.bias + coW + i * 16);
+        slope_r[i] = a.slope ? *reinterpret_cast<const float4v*>(a.slope + coW + i * 16) : float4v{1.f, 1.f, 1.f, 1.f};
+    }
+    float hw_r[NHEAD > 0 ? C::NT * 4 * NHEAD : 1];
+    if constexpr (NHEAD > 0) {
+#pragma unroll
+        for (int i = 0; i < C::NT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int k = 0; k < NHEAD; ++k) hw_r[(i * 4 + e) * NHEAD + k] = a.head_w[(coW + i * 16 + e) * NHEAD + k];
+    }
+    if (item0 < nitems) store_tile();
 
     for (int rr = 0; rr < RPB; ++rr) {
-        const int rx = bx * RPB + rr;
-        if (rx >= a.regions_x) break;
-        const int x0 = rx * RSX;
-        if (rr > 0) __syncthreads();                     // previous region's readers are done with the tiles
-
-        // ---- stage the input tile (zero outside the image / beyond CIN)
-        if constexpr (SRC == 1) {
-            const float ryr = (float)a.FH / (float)a.H, rxr = (float)a.FW / (float)a.W;
-            for (int e = tid; e < C::IH * C::IW; e += 256) {
-                const int iy = e / C::IW, ix = e - iy * C::IW;
-                const int n = img0, yy = y0 + iy, xx = x0 + ix;
-                float v[3] = {0.f, 0.f, 0.f};
-                if (n < a.B && yy < a.H && xx < a.W) {
-                    const DLerp ly = dlerp_coord(yy, ryr, a.FH), lx = dlerp_coord(xx, rxr, a.FW);
-                    const uint8_t* f = a.frames + (int64_t)n * a.FH * a.FW * 3;
-                    const uint8_t* r0 = f + (int64_t)ly.i0 * a.FW * 3;
-                    const uint8_t* r1 = f + (int64_t)ly.i1 * a.FW * 3;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const int ci = 2 - c;                       // BGR -> RGB
-                        const float s = dbilerp((float)r0[lx.i0 * 3 + ci], (float)r0[lx.i1 * 3 + ci],
-                                                (float)r1[lx.i0 * 3 + ci], (float)r1[lx.i1 * 3 + ci], lx.w, ly.w);
-                        v[c] = (s - 127.5f) * 0.0078125f;
-                    }
-                }
-                float* d = xin + e * C::CINS;
-                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = 0.f;
-            }
-        } else if constexpr (CIN % 4 == 0) {
-            constexpr int C4 = C::CINP / 4;
-            for (int e = tid; e < G * C::IH * C::IW * C4; e += 256) {
-                const int c4 = e % C4, pix_g = e / C4;
-                const int g = pix_g / (C::IH * C::IW), pix = pix_g - g * (C::IH * C::IW);
-                const int iy = pix / C::IW, ix = pix - iy * C::IW;
-                const int n = img0 + g, yy = y0 + iy, xx = x0 + ix;
-                float4v v = {0.f, 0.f, 0.f, 0.f};
-                if (n < a.B && yy < a.H && xx < a.W)
-                    v = *reinterpret_cast<const float4v*>(a.x + (((int64_t)n * a.H + yy) * a.W + xx) * CIN + c4 * 4);
-                float* d = xin + g * C::IMG + pix * C::CINS + c4 * 4;
-                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-            }
-        } else {
-            for (int e = tid; e < G * C::IMG; e += 256) {
-                const int g = e / C::IMG, r = e - g * C::IMG;
-                const int pix = r / C::CINS, ci = r - pix * C::CINS;
-                const int iy = pix / C::IW, ix = pix - iy * C::IW;
-                const int n = img0 + g, yy = y0 + iy, xx = x0 + ix;
-                float v = 0.f;
-                if (ci < CIN && n < a.B && yy < a.H && xx < a.W) v = a.x[(((int64_t)n * a.H + yy) * a.W + xx) * CIN + ci];
-                xin[e] = v;
-            }
-        }
+        const int item = item0 + rr;
+        if (item >= nitems) break;
+        const int zz = item / per_img, rem = item - zz * per_img;
+        const int ry = rem / a.regions_x, rx = rem - ry * a.regions_x;
+        const int y0 = ry * RSY, x0 = rx * RSX, img0 = zz * G;
+        const bool more = rr + 1 < RPB && item + 1 < nitems;
+        if (more) load_tile(item + 1);                   // global loads fly under this item's MFMAs
 
         float4v acc[C::NT][C::PT];
 #pragma unroll
@@ -202,20 +239,16 @@ __global__ __launch_bounds__(256) void dconv_mfma(DcArgs a) {
         // ---- epilogue: bias + PReLU
 #pragma unroll
         for (int i = 0; i < C::NT; ++i) {
-            const float4v bv = *reinterpret_cast<const float4v*>(a.bias + coW + i * 16);
-            float4v sv = {1.f, 1.f, 1.f, 1.f};
-            if (a.slope) sv = *reinterpret_cast<const float4v*>(a.slope + coW + i * 16);
 #pragma unroll
             for (int t = 0; t < C::PT; ++t) {
-                float4v v = acc[i][t] + bv;
+                float4v v = acc[i][t] + bias_r[i];
                 if (a.slope) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * sv[e];
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope_r[i][e];
                 }
                 acc[i][t] = v;
             }
         }
-
         if constexpr (POOL == 1) {
             // tiles: t = TR*row_in_wave + half; pool rows (2a, 2a+1) in registers, lanes (2b, 2b+1) by one shuffle
             constexpr int TR = RW / 16;
@@ -306,9 +339,8 @@ __global__ __launch_bounds__(256) void dconv_mfma(DcArgs a) {
                 for (int i = 0; i < C::NT; ++i)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int c = coW + i * 16 + e;
 #pragma unroll
-                        for (int k = 0; k < NHEAD; ++k) h[k] = __builtin_fmaf(acc[i][t][e], a.head_w[c * NHEAD + k], h[k]);
+                        for (int k = 0; k < NHEAD; ++k) h[k] = __builtin_fmaf(acc[i][t][e], hw_r[(i * 4 + e) * NHEAD + k], h[k]);
                     }
 #pragma unroll
                 for (int k = 0; k < NHEAD; ++k) {
@@ -351,6 +383,10 @@ __global__ __launch_bounds__(256) void dconv_mfma(DcArgs a) {
                 }
             }
         }
+        if (more) {
+            __syncthreads();                             // every wave is done with this item's tiles
+            store_tile();
+        }
     }
 }
 
@@ -371,7 +407,8 @@ static int launch_dc(const DcArgs& a0, hipStream_t s) {
     }
     constexpr int COUTP = (COUT + 15) / 16 * 16;
     static_assert(COUTP % (NTB * 16) == 0, "cout groups must tile COUTP");
-    dim3 grid(((a.regions_x + RPB - 1) / RPB) * a.regions_y, COUTP / (NTB * 16), (a.B + G - 1) / G);
+    const int nitems = a.regions_x * a.regions_y * ((a.B + G - 1) / G);
+    dim3 grid((nitems + RPB - 1) / RPB, COUTP / (NTB * 16), 1);
     const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
     auto kern = dconv_mfma<CIN, COUT, KH, KW, RH, RW, G, NTB, WN, TG, POOL, PK, RSY, RSX, NHEAD, RPB, SRC>;
     if (lds > 64 * 1024) {
@@ -394,22 +431,22 @@ extern "C" int fr_dconv_mfma_f32(int layer, const float* x, const float* w, cons
                                  float* y, int B, int H, int W, const float* head_w, const float* head_b,
                                  const uint8_t* frames, int FH, int FW, fr_stream_t stream) {
     FR_REQUIRE(w && bias && y && B > 0 && H > 0 && W > 0, "fr_dconv_mfma_f32: bad argument");
-    FR_REQUIRE(x || (layer == 0 && frames && FH > 0 && FW > 0), "fr_dconv_mfma_f32: no input");
-    DcArgs a{x, w, bias, slope, y, head_w, head_b, B, H, W, 0, 0, 0, 0, frames, FH, FW};
+    FR_REQUIRE((layer == 0) ? (frames && FH > 0 && FW > 0) : (x != nullptr), "fr_dconv_mfma_f32: no input");
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("FR_DET_DBG"); dbg = e ? atoi(e) : 0; }
+    DcArgs a{x, w, bias, slope, y, head_w, head_b, B, H, W, 0, 0, 0, 0, frames, FH, FW, dbg};
     hipStream_t s = fr_stream(stream);
     int rc = FR_OK;
     switch (layer) {
         //                  CIN COUT KH KW RH  RW  G NTB WN TG POOL PK RSY RSX NHEAD RPB SRC
-        case 0:  FR_REQUIRE(H >= 3 && W >= 3, "P1 input too small");                       // P-Net conv1+prelu+pool
-                 if (frames) rc = launch_dc<3, 10, 3, 3, 16, 32, 1, 1, 1, 9, 1, 2, 16, 32, 0, 4, 1>(a, s);
-                 else        rc = launch_dc<3, 10, 3, 3, 16, 32, 1, 1, 1, 9, 1, 2, 16, 32, 0, 4, 0>(a, s);
-                 break;
+        case 0:  FR_REQUIRE(H >= 3 && W >= 3 && frames, "P1 needs frames and a level of at least 3x3");
+                 rc = launch_dc<3, 12, 3, 3, 16, 32, 1, 1, 1, 9, 1, 2, 16, 32, 0, 8, 1>(a, s); break;     // P-Net conv1 (+resize, PReLU, pool)
         case 1:  FR_REQUIRE(H >= 3 && W >= 3, "P2 input too small");
-                 rc = launch_dc<10, 16, 3, 3, 8, 32, 1, 1, 1, 9, 0, 2, 8, 32, 0, 4, 0>(a, s); break;      // P-Net conv2
+                 rc = launch_dc<12, 16, 3, 3, 8, 32, 1, 1, 1, 9, 0, 2, 8, 32, 0, 8, 0>(a, s); break;      // P-Net conv2
         case 2:  FR_REQUIRE(H >= 3 && W >= 3 && head_w && head_b, "P3 needs head weights");
-                 rc = launch_dc<16, 32, 3, 3, 8, 32, 1, 2, 1, 9, 0, 2, 8, 32, 6, 4, 0>(a, s); break;      // P-Net conv3+heads
+                 rc = launch_dc<16, 32, 3, 3, 8, 32, 1, 2, 1, 9, 0, 2, 8, 32, 6, 8, 0>(a, s); break;      // P-Net conv3+heads
         case 10: FR_REQUIRE(H == 24 && W == 24, "R1 expects 24x24");                        // conv1 + 3x3/s2 pool -> 11x11
-                 rc = launch_dc<3, 28, 3, 3, 22, 22, 1, 2, 1, 9, 2, 3, 22, 22, 0, 1, 0>(a, s); break;
+                 rc = launch_dc<4, 28, 3, 3, 22, 22, 1, 2, 1, 9, 2, 3, 22, 22, 0, 4, 0>(a, s); break;
         case 11: FR_REQUIRE(H == 11 && W == 11, "R2 expects 11x11");                        // conv2 + 3x3/s2 pool -> 4x4
                  rc = launch_dc<28, 48, 3, 3, 9, 9, 2, 3, 1, 3, 2, 3, 8, 8, 0, 1, 0>(a, s); break;
         case 12: FR_REQUIRE(H == 4 && W == 4, "R3 expects 4x4");
@@ -419,7 +456,7 @@ extern "C" int fr_dconv_mfma_f32(int layer, const float* x, const float* w, cons
         case 14: FR_REQUIRE(H == 1 && W == 1, "R5 expects 1x1");
                  rc = launch_dc<128, 6, 1, 1, 1, 1, 64, 1, 1, 1, 0, 2, 1, 1, 0, 1, 0>(a, s); break;       // dense5_1|5_2
         case 20: FR_REQUIRE(H == 48 && W == 48, "O1 expects 48x48");                        // conv1 + 3x3/s2 pool -> 23x23
-                 rc = launch_dc<3, 32, 3, 3, 9, 46, 1, 2, 1, 9, 2, 3, 8, 46, 0, 1, 0>(a, s); break;
+                 rc = launch_dc<4, 32, 3, 3, 9, 46, 1, 2, 1, 9, 2, 3, 8, 46, 0, 6, 0>(a, s); break;
         case 21: FR_REQUIRE(H == 23 && W == 23, "O2 expects 23x23");                        // conv2 + 3x3/s2 pool -> 10x10
                  rc = launch_dc<32, 64, 3, 3, 7, 21, 1, 4, 1, 3, 2, 3, 6, 20, 0, 1, 0>(a, s); break;
         case 22: FR_REQUIRE(H == 10 && W == 10, "O3 expects 10x10");                        // conv3 + 2x2/s2 pool -> 4x4

@@ -322,7 +322,8 @@ extern "C" int fr_box_refine(float* boxes, const float* aux, int naux, const int
 }
 
 // ------------------------------------------------------------------ crop + resize + normalise
-// Zero-padded crop of the (1-based inclusive) box trunc(b), bilinear to size x size, RGB normalised.
+// Zero-padded crop of the (1-based inclusive) box trunc(b), bilinear to size x size, RGB normalised,
+// written as 4-channel pixels (RGB0) so that the first R/O-Net conv reads 16-byte pixels.
 // One block per candidate slot; invalid slots (>= count, or empty boxes) are zero-filled.
 __global__ __launch_bounds__(256) void crop_resize_norm(const uint8_t* __restrict__ frames, int H, int W,
                                                         const float* __restrict__ boxes,
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256) void crop_resize_norm(const uint8_t* __restric
                                                         float* __restrict__ out) {
     const int slot = blockIdx.x;
     const int f = slot / cap, i = slot - f * cap;
-    float* o = out + (int64_t)slot * size * size * 3;
+    float* o = out + (int64_t)slot * size * size * 4;
     const float4 b = *reinterpret_cast<const float4*>(boxes + (int64_t)slot * 4);
     const int x1 = (int)truncf(b.x), y1 = (int)truncf(b.y), x2 = (int)truncf(b.z), y2 = (int)truncf(b.w);
     const int tw = x2 - x1 + 1, th = y2 - y1 + 1;
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256) void crop_resize_norm(const uint8_t* __restric
             for (int ch = 0; ch < 3; ++ch)
                 v[ch] = (bilerp(p[0][0][ch], p[0][1][ch], p[1][0][ch], p[1][1][ch], lx.w, ly.w) - 127.5f) * 0.0078125f;
         }
-        o[t * 3 + 0] = v[0]; o[t * 3 + 1] = v[1]; o[t * 3 + 2] = v[2];
+        *reinterpret_cast<float4*>(o + t * 4) = make_float4(v[0], v[1], v[2], 0.f);     // 4th channel = 0 (16-B pixels)
     }
 }
 

@@ -60,10 +60,10 @@ class _DConv:
 
 
 # layer id -> (cin, cout, kh, kw, ntb): must mirror the table in csrc/dconv_mfma.hip
-MFMA_LAYERS = {0: (3, 10, 3, 3, 1), 1: (10, 16, 3, 3, 1), 2: (16, 32, 3, 3, 2),
-               10: (3, 28, 3, 3, 2), 11: (28, 48, 3, 3, 3), 12: (48, 64, 2, 2, 4), 13: (64, 128, 3, 3, 4),
+MFMA_LAYERS = {0: (3, 12, 3, 3, 1), 1: (12, 16, 3, 3, 1), 2: (16, 32, 3, 3, 2),
+               10: (4, 28, 3, 3, 2), 11: (28, 48, 3, 3, 3), 12: (48, 64, 2, 2, 4), 13: (64, 128, 3, 3, 4),
                14: (128, 6, 1, 1, 1),
-               20: (3, 32, 3, 3, 2), 21: (32, 64, 3, 3, 4), 22: (64, 64, 3, 3, 4), 23: (64, 128, 2, 2, 4),
+               20: (4, 32, 3, 3, 2), 21: (32, 64, 3, 3, 4), 22: (64, 64, 3, 3, 4), 23: (64, 128, 2, 2, 4),
                24: (128, 256, 3, 3, 4), 25: (256, 16, 1, 1, 1)}
 
 
@@ -72,8 +72,15 @@ class _MConv:
     CinP = Cin rounded up to 4 and CP = NTB*16 (+16 when NTB is even: LDS bank spread)."""
 
     def __init__(self, layer, w, b, slope, device, head=None):
-        cin, cout, kh, kw, ntb = MFMA_LAYERS[layer]
-        assert tuple(w.shape) == (cout, cin, kh, kw), (layer, tuple(w.shape))
+        cin, cout, kh, kw, ntb = MFMA_LAYERS[layer]      # packed sizes: real channels are zero-padded up to them
+        rcout, rcin = w.shape[0], w.shape[1]
+        assert tuple(w.shape[2:]) == (kh, kw) and rcout <= cout and rcin <= cin, (layer, tuple(w.shape))
+        wfull = torch.zeros((cout, cin, kh, kw), dtype=torch.float32)
+        wfull[:rcout, :rcin] = w
+        w = wfull
+        bfull = torch.zeros(cout); bfull[:rcout] = b; b = bfull
+        if slope is not None:
+            sfull = torch.zeros(cout); sfull[:rcout] = slope; slope = sfull
         self.layer, self.cin, self.cout, self.kh, self.kw = layer, cin, cout, kh, kw
         cinp = -(-cin // 4) * 4
         cp = ntb * 16 + (16 if ntb % 2 == 0 else 0)
@@ -240,7 +247,7 @@ class MTCNNHIP:
                 trace.update(stage1_boxes=b1, stage1_scores=s1, stage1_counts=c1)
             # ---- stage 2
             B2 = N * self.cap_p
-            crops = self._f32(B2, 24, 24, 3)
+            crops = self._f32(B2, 24, 24, 4)
             lib.fr_crop_resize_norm(_lib.ptr(frames), N, H, W, _lib.ptr(b1), _lib.ptr(c1), self.cap_p, 24,
                                     _lib.ptr(crops), self._s)
             head2 = self.rnet(crops, B2)
@@ -255,7 +262,7 @@ class MTCNNHIP:
                              stage2_counts=c2)
             # ---- stage 3
             B3 = N * self.cap_r
-            crops3 = self._f32(B3, 48, 48, 3)
+            crops3 = self._f32(B3, 48, 48, 4)
             lib.fr_crop_resize_norm(_lib.ptr(frames), N, H, W, _lib.ptr(b2), _lib.ptr(c2), self.cap_r, 48,
                                     _lib.ptr(crops3), self._s)
             head3 = self.onet(crops3, B3)

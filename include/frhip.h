@@ -116,9 +116,10 @@ int fr_dconv_f32(const float* x, const float* w, const float* bias, const float*
  * 10..14 = R-Net conv1(+3x3/s2 pool), conv2(+3x3/s2 pool), conv3, dense4, dense5_1|5_2;
  * 20..25 = O-Net conv1(+pool), conv2(+pool), conv3(+2x2 pool), conv4, dense5, dense6_1|6_2|6_3.
  * x f32 NHWC [B,H,W,Cin]; w packed [cout_group][tap][CinP][CP] (mtcnn.py _MConv); bias/slope padded to
- * the group size; slope NULL = no PReLU.  Layer 0 may instead take `frames` (u8 BGR [B,FH,FW,3]) with
- * x == NULL: the pyramid level (H x W) is then resized on the fly inside the tile load, with the same
- * arithmetic as fr_pyramid_resize_norm. */
+ * the group size; slope NULL = no PReLU.  Channel counts are padded to multiples of 4 (P-Net conv1 writes
+ * 12 channels, R/O-Net conv1 read 4).  Layer 0 takes `frames` (u8 BGR [B,FH,FW,3]) instead of x: the
+ * pyramid level (H x W) is resized on the fly inside the tile load, with the same arithmetic as
+ * fr_pyramid_resize_norm.  Blocks walk several tiles, prefetching the next tile into registers. */
 int fr_dconv_mfma_f32(int layer, const float* x, const float* w, const float* bias, const float* slope,
                       float* y, int B, int H, int W, const float* head_w, const float* head_b,
                       const uint8_t* frames, int FH, int FW, fr_stream_t stream);
@@ -148,7 +149,7 @@ int fr_sort_nms(const float* boxes, const float* scores, const float* aux, int n
 int fr_box_refine(float* boxes, const float* aux, int naux, const int32_t* counts, int L, int cap,
                   int mode, fr_stream_t stream);
 /* zero-padded crop of trunc(box) (1-based inclusive) + bilinear resize to size x size + normalise
- * -> f32 NHWC(3) [nframes*cap,size,size,3]; slots >= count are zero-filled. */
+ * -> f32 NHWC [nframes*cap,size,size,4] (RGB + a zero channel); slots >= count are zero-filled. */
 int fr_crop_resize_norm(const uint8_t* frames, int nframes, int H, int W, const float* boxes,
                         const int32_t* counts, int cap, int size, float* out, fr_stream_t stream);
 /* R/O-Net decision: head f32 [L*cap,nh] = (logit0, logit1, reg0..3[, lm0..9]); keeps slots with
