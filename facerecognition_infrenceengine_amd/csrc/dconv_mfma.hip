@@ -440,7 +440,7 @@ extern "C" int fr_dconv_mfma_f32(int layer, const float* x, const float* w, cons
     switch (layer) {
         //                  CIN COUT KH KW RH  RW  G NTB WN TG POOL PK RSY RSX NHEAD RPB SRC
         case 0:  FR_REQUIRE(H >= 3 && W >= 3 && frames, "P1 needs frames and a level of at least 3x3");
-                 rc = launch_dc<3, 12, 3, 3, 16, 32, 1, 1, 1, 9, 1, 2, 16, 32, 0, 8, 1>(a, s); break;     // P-Net conv1 (+resize, PReLU, pool)
+                 rc = launch_dc<3, 12, 3, 3, 16, 32, 1, 1, 1, 9, 1, 2, 16, 32, 0, 1, 1>(a, s); break;     // P-Net conv1 (+resize, PReLU, pool)
         case 1:  FR_REQUIRE(H >= 3 && W >= 3, "P2 input too small");
                  rc = launch_dc<12, 16, 3, 3, 8, 32, 1, 1, 1, 9, 0, 2, 8, 32, 0, 8, 0>(a, s); break;      // P-Net conv2
         case 2:  FR_REQUIRE(H >= 3 && W >= 3 && head_w && head_b, "P3 needs head weights");
