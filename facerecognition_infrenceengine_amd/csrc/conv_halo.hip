@@ -30,9 +30,6 @@ struct HaloP {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 #define HK 64          // channels per chunk
-#define XROWS 320      // halo rows capacity (>= (TH+2)*(W+2))
-#define NXI 5          // halo LDS-DMA instructions per thread per chunk (8 waves x 5 x 8 rows)
-#define NPT 13         // pixel tiles (196 px)
 
 
 // scheduling pattern for one half step: 4+PT ds_read_b128 (+ ~3 address VALU each) spread over 4*PT MFMAs
@@ -55,16 +52,20 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
         }                                                                                   \
     } while (0)
 
-template <int WN, bool STAMPS>
-__global__ __launch_bounds__(512) void conv_halo_kernel(HaloP p) {
+// WN: 64-cout groups per block; NPT: 16-pixel MFMA tiles per M tile; XROWS: halo row capacity (multiple of 64,
+// >= (TH+2)*(W+2)); NXBUF: halo buffers (1 when Cin == 64: a single chunk); MINW: waves per SIMD to fit
+// (4 = two blocks per CU).
+template <int WN, int NPT, int XROWS, int NXBUF, int MINW, bool STAMPS>
+__global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BN = 64 * WN;
     constexpr int WP = 8 / WN;
     constexpr int PT = (NPT + WP - 1) / WP;
     constexpr int NWI = BN / 64;                      // weight LDS-DMA instructions per thread per step
+    constexpr int NXI = XROWS / 64;                   // halo LDS-DMA instructions per thread per chunk
     extern __shared__ __attribute__((aligned(16))) half_t lds[];
-    half_t* xs = lds;                                 // [2][XROWS][HK]
-    half_t* ws = lds + 2 * XROWS * HK;                // [2][BN][HK]
+    half_t* xs = lds;                                 // [NXBUF][XROWS][HK]
+    half_t* ws = lds + NXBUF * XROWS * HK;            // [2][BN][HK]
 
     if (p.dbg & 16) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloP p) {
     for (int i = 0; i < NWI; ++i) woff[i] = (unsigned)(((cout0 + (wave * NWI + i) * 8 + lrow) * K + schunk * 8) * 2);
 
     auto issue_x = [&](int c) {
-        half_t* dst = xs + (c & 1) * XROWS * HK;
+        half_t* dst = xs + (c & (NXBUF - 1)) * XROWS * HK;
 #pragma unroll
         for (int i = 0; i < NXI; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(dst + (wave * NXI + i) * 8 * HK), 16, xoff[i],
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloP p) {
     int4v a0[4], b0[PT], a1[4], b1[PT];       // 8 halves each, kept as 4 dwords (no per-element repacking)
     auto read_frags = [&](int4v (&a)[4], int4v (&b)[PT], int q, int c, int toff, int kh, int kk) {
         const half_t* wl = ws + (q & 1) * BN * HK + (wn * 64) * HK;
-        const char* xl = reinterpret_cast<const char*>(xs + (c & 1) * XROWS * HK) + toff * (HK * 2);   // scalar part
+        const char* xl = reinterpret_cast<const char*>(xs + (c & (NXBUF - 1)) * XROWS * HK) + toff * (HK * 2);   // scalar part
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = i * 16 + fr;
@@ -318,11 +319,13 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloP p) {
 #endif
 }
 
-template <int WN>
+template <int WN, int NPT, int XROWS, int NXBUF, int MINW>
 static int launch_halo(const HaloP& p, hipStream_t s) {
     constexpr int BN = 64 * WN;
-    const size_t lds = (size_t)(2 * XROWS * HK + 2 * BN * HK) * sizeof(half_t);
-    auto kern = p.stamps ? conv_halo_kernel<WN, true> : conv_halo_kernel<WN, false>;
+    constexpr size_t opnd = (size_t)(NXBUF * XROWS * HK + 2 * BN * HK) * sizeof(half_t);
+    constexpr size_t epi = (size_t)NPT * 16 * (BN + 8) * sizeof(half_t);          // output staging tile
+    constexpr size_t lds = opnd > epi ? opnd : epi;
+    auto kern = p.stamps ? conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, true> : conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, false>;
     static bool done[2] = {false, false};
     if (!done[p.stamps ? 1 : 0]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -341,9 +344,13 @@ static int launch_halo(const HaloP& p, hipStream_t s) {
 int fr_conv_halo_try(const fr_conv_args* a, hipStream_t s) {
     if (!(a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->H == a->W && a->out_f32_partial == nullptr))
         return 0;
-    if (!(a->Cin % 64 == 0 && a->Cout % 128 == 0)) return 0;
+    if (a->Cin % 64 != 0 || a->Cout % 64 != 0) return 0;
     int TH;
-    if (a->H == 14) TH = 14; else if (a->H == 28) TH = 7; else return 0;
+    if (a->H == 14 && a->Cout % 128 == 0) TH = 14;
+    else if (a->H == 28 && a->Cout % 128 == 0) TH = 7;
+    else if (a->H == 56 && a->Cin == 64 && a->Cout == 64) TH = 4;        // single-chunk variants (one halo buffer)
+    else if (a->H == 112 && a->Cin == 64 && a->Cout == 64) TH = 2;
+    else return 0;
     if ((int64_t)a->B * a->H * a->W * a->Cin * 2 >= (1ll << 31) || (int64_t)a->Cout * 9 * a->Cin * 2 >= (1ll << 31)) return 0;
     HaloP p;
     p.x = (const half_t*)a->x; p.w = (const half_t*)a->w; p.y = (half_t*)a->y;
@@ -354,6 +361,9 @@ int fr_conv_halo_try(const fr_conv_args* a, hipStream_t s) {
     p.wbytes = (unsigned)((int64_t)a->Cout * 9 * a->Cin * 2);
     { static long long sp = -1; if (sp < 0) { const char* e = getenv("FR_DBG_STAMPS"); sp = e ? strtoll(e, nullptr, 0) : 0; } p.stamps = (unsigned long long*)sp; }
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("FR_CONV_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
-    int rc = (a->Cout % 256 == 0) ? launch_halo<4>(p, s) : launch_halo<2>(p, s);
+    int rc;
+    if (a->H == 56) rc = launch_halo<1, 14, 384, 1, 4>(p, s);
+    else if (a->H == 112) rc = launch_halo<1, 14, 512, 1, 4>(p, s);
+    else rc = (a->Cout % 256 == 0) ? launch_halo<4, 13, 320, 2, 2>(p, s) : launch_halo<2, 13, 320, 2, 2>(p, s);
     return rc == FR_OK ? 1 : rc;
 }

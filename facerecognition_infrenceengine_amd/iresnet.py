@@ -131,13 +131,17 @@ class IResNetHIP:
             e0.record()
             self.lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
             e1.record()
-            # mirror of the C dispatch (fr_conv_nhwc_f16): halo kernel for 3x3/s1 at 14x14 and 28x28
-            if c.k == 3 and c.stride == 1 and H == W and H in (14, 28) and c.cin % 64 == 0 and c.cout % 128 == 0 \
-                    and partial is None:
-                variant = "conv_halo_kernel<%d, false>" % (4 if c.cout % 256 == 0 else 2)
-            else:
-                variant = "conv_mfma_kernel<%d, %s, true>" % (2 if c.cout % 128 == 0 else 1,
-                                                             "true" if c.cin == 8 else "false")
+            # mirror of the C dispatch (fr_conv_nhwc_f16 -> fr_conv_halo_try): halo kernel for 3x3/s1 body convs
+            halo = None
+            if c.k == 3 and c.stride == 1 and H == W and partial is None and c.cin % 64 == 0:
+                if H in (14, 28) and c.cout % 128 == 0:
+                    halo = "conv_halo_kernel<%d, 13, 320, 2, 2, false>" % (4 if c.cout % 256 == 0 else 2)
+                elif H == 56 and c.cin == 64 and c.cout == 64:
+                    halo = "conv_halo_kernel<1, 14, 384, 1, 4, false>"
+                elif H == 112 and c.cin == 64 and c.cout == 64:
+                    halo = "conv_halo_kernel<1, 14, 512, 1, 4, false>"
+            variant = halo or "conv_mfma_kernel<%d, %s, true>" % (2 if c.cout % 128 == 0 else 1,
+                                                                  "true" if c.cin == 8 else "false")
             kreal = 27 if c.cin == 8 else c.k * c.k * c.cin       # algorithmic K (stem: 3 real channels)
             self.profile.append((variant, 2.0 * B * Ho * Wo * c.cout * kreal, e0, e1))
         else:

@@ -68,6 +68,9 @@ def _conv_case(lib, B, H, W, Cin, Cout, k, stride, pad, bias_mode, slope, residu
     (1, 56, 56, 64, 64, 3, 1, 1, 1, True, False),        # 64-cout tile shape
     (5, 7, 7, 512, 512, 3, 1, 1, 0, False, True),        # 7x7 stage, ragged M = 245
     (1, 9, 5, 64, 64, 3, 1, 1, 1, True, True),           # tiny odd image
+    (3, 56, 56, 64, 64, 3, 1, 1, 0, False, True),        # halo kernel, single-chunk 56x56 variant + residual
+    (2, 112, 112, 64, 64, 3, 1, 1, 1, True, False),      # halo kernel, 112x112 variant
+    (2, 28, 28, 128, 128, 3, 1, 1, 0, False, True),      # halo kernel, BN = 128 variant + residual
 ])
 def test_conv_layer_vs_torch(lib, case):
     _conv_case(lib, *case, seed=hash(case) & 0xffff)
