@@ -55,7 +55,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // WN: 64-cout groups per block; NPT: 16-pixel MFMA tiles per M tile; XROWS: halo row capacity (multiple of 64,
 // >= (TH+2)*(W+2)); NXBUF: halo buffers (1 when Cin == 64: a single chunk); MINW: waves per SIMD to fit
 // (4 = two blocks per CU).
-template <int WN, int NPT, int XROWS, int NXBUF, int MINW, bool STAMPS>
+// LEAN: one halo buffer, one fragment set, <= 128 VGPRs -> TWO blocks per CU (16 waves): the fixed cost of a
+// block (first loads, epilogue: ~30 % of a 28x28 tile) and its barrier stalls are covered by the neighbour.
+template <int WN, int NPT, int XROWS, int NXBUF, int MINW, bool STAMPS, bool LEAN = false>
 __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BN = 64 * WN;
@@ -183,6 +185,32 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
 #pragma unroll
     for (int j = 0; j < PT; ++j) b0[j] = b1[j] = int4v{0, 0, 0, 0};
 
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, s01 = 0, s12 = 0, s23 = 0, s34 = 0, s45 = 0;
+    if constexpr (LEAN) {
+        static_assert(!LEAN || NXBUF == 1, "lean variant keeps one halo buffer");
+        issue_x(0);
+        issue_w(0);
+        int tap = 0, c = 0, toff = 0, kw = 0, kh = 0;
+        for (int q = 0; q < nq; ++q) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // W(q) (and a halo issued at the last chunk end)
+            __builtin_amdgcn_s_barrier();
+            if (q + 1 < nq) issue_w(q + 1);
+            read_frags(a0, b0, q, c, toff, kh, 0);
+            mfma_all(a0, b0);
+            read_frags(a1, b1, q, c, toff, kh, 1);
+            mfma_all(a1, b1);
+            ++tap; ++kw; ++toff;
+            if (kw == 3) { kw = 0; toff += HW - 3; ++kh; }
+            if (tap == 9) {
+                tap = 0; kw = 0; toff = 0; kh = 0; ++c;
+                if (c < nchunk) {                                    // reload the single halo buffer
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                    // every wave is done reading chunk c-1
+                    issue_x(c);
+                }
+            }
+        }
+    } else {
     issue_x(0);
     issue_w(0);
     if (nq > 1) issue_w(1);
@@ -193,7 +221,6 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
     read_frags(a0, b0, 0, 0, 0, 0, 0);
     int tap = 0, c = 0, toff = 0, kw = 0, kh = 0;
     bool x_inflight = false;               // a halo was issued at the previous mid-step (after the W loads)
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, s01 = 0, s12 = 0, s23 = 0, s34 = 0, s45 = 0;
     // One K step.  LDS-DMA issue costs ~100 cycles per piece and sits in the wave's in-order stream, so the
     // four W pieces of step q+2 are scheduled INTO the MFMA stream of half 1 (stamps: 390 of 2680 cycles per
     // step when issued as a block after the barrier); fragment reads are front-loaded in each MFMA stream so
@@ -255,6 +282,7 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
     int q = 0;
     for (; q + 2 < nq; ++q) step(q, std::true_type{});
     for (; q < nq; ++q) step(q, std::false_type{});
+    }
     if (STAMPS && p.stamps && lane == 0) {
         unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
         o[0] = s01; o[1] = s12; o[2] = s23; o[3] = s34; o[4] = s45;
@@ -319,13 +347,14 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
 #endif
 }
 
-template <int WN, int NPT, int XROWS, int NXBUF, int MINW>
+template <int WN, int NPT, int XROWS, int NXBUF, int MINW, bool LEAN = false>
 static int launch_halo(const HaloP& p, hipStream_t s) {
     constexpr int BN = 64 * WN;
     constexpr size_t opnd = (size_t)(NXBUF * XROWS * HK + 2 * BN * HK) * sizeof(half_t);
     constexpr size_t epi = (size_t)NPT * 16 * (BN + 8) * sizeof(half_t);          // output staging tile
     constexpr size_t lds = opnd > epi ? opnd : epi;
-    auto kern = p.stamps ? conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, true> : conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, false>;
+    auto kern = (p.stamps && !LEAN) ? conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, true, LEAN>
+                                    : conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, false, LEAN>;
     static bool done[2] = {false, false};
     if (!done[p.stamps ? 1 : 0]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -364,6 +393,13 @@ int fr_conv_halo_try(const fr_conv_args* a, hipStream_t s) {
     int rc;
     if (a->H == 56) rc = launch_halo<1, 14, 384, 1, 4>(p, s);
     else if (a->H == 112) rc = launch_halo<1, 14, 512, 1, 4>(p, s);
-    else rc = (a->Cout % 256 == 0) ? launch_halo<4, 13, 320, 2, 2>(p, s) : launch_halo<2, 13, 320, 2, 2>(p, s);
+    else {
+        // FR_HALO_LEAN bit 0: 28x28 layers, bit 1: 14x14 layers run as two lean blocks per CU (default 3 = both)
+        static int lean = -1;
+        if (lean < 0) { const char* e = getenv("FR_HALO_LEAN"); lean = e ? atoi(e) : 3; }
+        if ((lean & 1) && a->H == 28) rc = launch_halo<2, 13, 320, 1, 4, true>(p, s);
+        else if ((lean & 2) && a->H == 14) rc = launch_halo<2, 13, 256, 1, 4, true>(p, s);
+        else rc = (a->Cout % 256 == 0) ? launch_halo<4, 13, 320, 2, 2>(p, s) : launch_halo<2, 13, 320, 2, 2>(p, s);
+    }
     return rc == FR_OK ? 1 : rc;
 }
