@@ -36,6 +36,9 @@ SIGNATURES = {
     "fr_gallery_match_f32": (_I, [_P, _P, _I, _L, _I, _L, _P, _P, _P, _Z, _P]),
     "fr_f32_to_f16": (_I, [_P, _P, _L, _P]),
     "fr_match_decide": (_I, [_P, _P, _I, _F, _F, _P, _P]),
+    "fr_gallery_first_above_f32": (_I, [_P, _P, _I, _L, _I, _F, _I, _L, _P, _P, _P, _Z, _P]),
+    "fr_cosine_matrix_f32": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "fr_mean_rows_f32": (_I, [_P, _I, _I, _P, _P]),
     "fr_conv_nhwc_f16": (_I, [C.POINTER(ConvArgs), _P]),
     "fr_fc_reduce_l2norm": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
     "fr_warp_affine_5pt": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P]),

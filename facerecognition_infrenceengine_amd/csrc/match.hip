@@ -208,3 +208,106 @@ extern "C" int fr_f32_to_f16(const float* x, void* out, int64_t n, fr_stream_t s
     FR_CHECK_LAUNCH("f32_to_f16");
     return FR_OK;
 }
+
+// ---------------------------------------------------------------- next-row consumers of the scan
+// First row (lowest index) whose dot with the query exceeds a threshold: the enrolment duplicate check
+// (`sim > duplicate_threshold`, first hit returns: /root/reference/trainingServer.py:181-194) and the
+// unknown-person cluster assignment (`similarity >= 0.65`, first hit breaks:
+// /root/reference/peopleCount.py:441-449).  One wave per (query, 64-row slab): coalesced row reads,
+// wave reduction of the dot, running minimum of the passing row index.
+__global__ __launch_bounds__(256) void gallery_first_above(const float* __restrict__ Q, const float* __restrict__ G,
+                                                           int F, int64_t N, float thr, int inclusive,
+                                                           unsigned long long* __restrict__ out_min) {
+    const int f = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* q = Q + (int64_t)f * GD;
+    float qv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) qv[k] = q[lane * 8 + k];
+    unsigned long long best = ~0ull;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < N; r += (int64_t)gridDim.x * 4) {
+        const float4* g = reinterpret_cast<const float4*>(G + r * GD + lane * 8);
+        const float4 g0 = g[0], g1 = g[1];
+        float s = qv[0] * g0.x + qv[1] * g0.y + qv[2] * g0.z + qv[3] * g0.w + qv[4] * g1.x + qv[5] * g1.y +
+                  qv[6] * g1.z + qv[7] * g1.w;
+        s = wave_sum(s);
+        const bool pass = inclusive ? (s >= thr) : (s > thr);
+        if (pass) {
+            unsigned long long key = ((unsigned long long)r << 32) | __float_as_uint(s);
+            best = key < best ? key : best;
+        }
+    }
+    if (lane == 0 && best != ~0ull) atomicMin(out_min + f, best);
+}
+
+__global__ void first_above_finish(const unsigned long long* __restrict__ mins, int F, int64_t row_offset,
+                                   int64_t* __restrict__ out_idx, float* __restrict__ out_score) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    unsigned long long k = mins[f];
+    if (k == ~0ull) { out_idx[f] = -1; out_score[f] = 0.f; }
+    else { out_idx[f] = (int64_t)(k >> 32) + row_offset; out_score[f] = __uint_as_float((unsigned)(k & 0xffffffffu)); }
+}
+
+extern "C" int fr_gallery_first_above_f32(const float* Q, const float* G, int F, int64_t N, int D, float thr,
+                                          int inclusive, int64_t row_offset, int64_t* out_idx, float* out_score,
+                                          void* workspace, size_t workspace_bytes, fr_stream_t stream) {
+    FR_REQUIRE(D == GD, "fr_gallery_first_above_f32: D must be %d", GD);
+    if (F <= 0) return FR_OK;
+    FR_REQUIRE(Q && out_idx && out_score && (G || N == 0) && N >= 0 && N < (1ll << 31), "fr_gallery_first_above_f32: bad argument");
+    FR_REQUIRE(workspace && workspace_bytes >= (size_t)F * 8, "fr_gallery_first_above_f32: workspace needs %zu bytes", (size_t)F * 8);
+    hipStream_t s = fr_stream(stream);
+    unsigned long long* mins = reinterpret_cast<unsigned long long*>(workspace);
+    if (hipMemsetAsync(mins, 0xff, (size_t)F * 8, s) != hipSuccess) { fr_set_error("fr_gallery_first_above_f32: memset failed"); return FR_E_LAUNCH; }
+    if (N > 0) {
+        int bx = (int)((N + 3) / 4); if (bx > 1024) bx = 1024;
+        gallery_first_above<<<dim3(bx, F), 256, 0, s>>>(Q, G, F, N, thr, inclusive, mins);
+        FR_CHECK_LAUNCH("gallery_first_above");
+    }
+    first_above_finish<<<fr_cdiv(F, 64), 64, 0, s>>>(mins, F, row_offset, out_idx, out_score);
+    FR_CHECK_LAUNCH("first_above_finish");
+    return FR_OK;
+}
+
+// out[f][n] = dot(A[f], B[n]) / (|A[f]| |B[n]|): the pose-consistency matrix of the enrolment path
+// (/root/reference/trainingServer.py:202-214); one wave per pair.
+__global__ void cosine_matrix(const float* __restrict__ A, const float* __restrict__ B, int F, int N, int D,
+                              float* __restrict__ out) {
+    const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (pair >= F * N) return;
+    const int f = pair / N, n = pair - f * N;
+    float ab = 0.f, aa = 0.f, bb = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float a = A[(int64_t)f * D + c], b = B[(int64_t)n * D + c];
+        ab += a * b; aa += a * a; bb += b * b;
+    }
+    ab = wave_sum(ab); aa = wave_sum(aa); bb = wave_sum(bb);
+    if (lane == 0) out[pair] = ab / (sqrtf(aa) * sqrtf(bb));
+}
+
+extern "C" int fr_cosine_matrix_f32(const float* A, const float* B, int F, int N, int D, float* out,
+                                    fr_stream_t stream) {
+    if (F <= 0 || N <= 0) return FR_OK;
+    FR_REQUIRE(A && B && out && D > 0, "fr_cosine_matrix_f32: bad argument");
+    cosine_matrix<<<fr_cdiv((int64_t)F * N, 4), 256, 0, fr_stream(stream)>>>(A, B, F, N, D, out);
+    FR_CHECK_LAUNCH("cosine_matrix");
+    return FR_OK;
+}
+
+// mean of K rows (np.mean(face_embeddings, axis=0), /root/reference/trainingServer.py:355; the unknown-person
+// running mean /root/reference/peopleCount.py:79): out[c] = (x[0][c] + ... + x[K-1][c]) / K, summed in row order.
+__global__ void mean_rows(const float* __restrict__ x, int K, int D, float* __restrict__ out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= D) return;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += x[(int64_t)k * D + c];
+    out[c] = s / (float)K;
+}
+
+extern "C" int fr_mean_rows_f32(const float* x, int K, int D, float* out, fr_stream_t stream) {
+    FR_REQUIRE(x && out && K > 0 && D > 0, "fr_mean_rows_f32: bad argument");
+    mean_rows<<<fr_cdiv(D, 256), 256, 0, fr_stream(stream)>>>(x, K, D, out);
+    FR_CHECK_LAUNCH("mean_rows");
+    return FR_OK;
+}

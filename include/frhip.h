@@ -57,6 +57,20 @@ int fr_match_decide(const int64_t* idx, const float* score, int F, float thr, fl
                     int32_t* decision, fr_stream_t stream);
 
 
+/* ------------------------------------------------- enrolment / clustering consumers of the scan ----
+ * First (lowest) row whose dot with the query is > thr (inclusive != 0: >= thr); idx -1 / score 0 when none.
+ * Duplicate check `sim > 0.4`, first hit returns (trainingServer.py:181-194); unknown-person assignment
+ * `similarity >= 0.65`, first hit breaks (peopleCount.py:441-449).  Rows must be unit length for the
+ * dot to be the reference's cosine.  workspace: F * 8 bytes. */
+int fr_gallery_first_above_f32(const float* Q, const float* G, int F, int64_t N, int D, float thr,
+                               int inclusive, int64_t row_offset, int64_t* out_idx, float* out_score,
+                               void* workspace, size_t workspace_bytes, fr_stream_t stream);
+/* out[f][n] = cosine(A[f], B[n]): pose-consistency matrix (trainingServer.py:202-214) */
+int fr_cosine_matrix_f32(const float* A, const float* B, int F, int N, int D, float* out,
+                         fr_stream_t stream);
+/* out = mean of K rows, summed in row order (np.mean(.., axis=0): trainingServer.py:355, peopleCount.py:79) */
+int fr_mean_rows_f32(const float* x, int K, int D, float* out, fr_stream_t stream);
+
 /* ---------------------------------------------------------------- embed ----
  * a-4  ArcFace IResNet conv stack (inside FaceAnalysis.get, infrenceServer.py:528).
  * Implicit-GEMM convolution on MFMA, NHWC f16 activations, f32 accumulate:
