@@ -153,8 +153,18 @@ def main():
     dom = max(per, key=lambda k: per[k][2])
     calls, flops, secs = per[dom]
     achieved = flops / secs / 1e12
+    # HBM traffic per launch of that kernel: PMC counters from a separate rocprofv3 pass (profiles/, see the
+    # note inside the file for the gfx950 FETCH_SIZE correction); None when no record matches the kernel
+    traffic = None
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        hits = [v for k, v in rec.items() if k.startswith(dom + " ") and "hbm_bytes_per_launch_corrected" in v]
+        if hits:
+            traffic = hits[0]["hbm_bytes_per_launch_corrected"]
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "launches_per_step": calls, "avg_launch_us": round(secs / calls * 1e6, 2),
                 "algorithmic_gflop_per_launch": round(flops / calls / 1e9, 3)}
 
