@@ -11,6 +11,9 @@
 #define GD 512          // embedding dim
 #define QPAD 516        // LDS row stride (floats) for the query tile: breaks the 2 KB bank stride
 #define QG 32           // queries per group (MFMA N)
+#ifndef FR_TOPK
+#define FR_TOPK 4
+#endif
 
 struct BestPair { float s; int64_t i; };
 
@@ -309,5 +312,180 @@ extern "C" int fr_mean_rows_f32(const float* x, int K, int D, float* out, fr_str
     FR_REQUIRE(x && out && K > 0 && D > 0, "fr_mean_rows_f32: bad argument");
     mean_rows<<<fr_cdiv(D, 256), 256, 0, fr_stream(stream)>>>(x, K, D, out);
     FR_CHECK_LAUNCH("mean_rows");
+    return FR_OK;
+}
+
+// ---------------------------------------------------------------- f16 gallery scan + exact f32 re-rank
+// For 1 M .. 10 M row galleries (BASELINE configs C4/C5) the scan runs on the f16 matrix cores over an f16
+// copy of the gallery (half the HBM bytes of the f32 rows, 16x the f32 matrix rate):
+// v_mfma_f32_32x32x16_f16 with A = 32 gallery rows, B = 32 queries, so (as in the f32 scan) a lane owns one
+// query and 16 rows per tile and keeps its top-FR_TOPK candidates locally.  The per-block candidates are then
+// merged and RE-SCORED EXACTLY in f32 against the f32 rows; the final pick is max f32 score, lowest row on
+// ties - the reference's rule - so f16 rounding can only matter if the true winner fell out of the f16 top-4.
+#define QG16 4            // query groups (of 32) per pass: 128 queries share one sweep of the gallery
+
+struct Top4 { float s[FR_TOPK]; int i[FR_TOPK]; };
+
+__device__ __forceinline__ void top4_insert(Top4& t, float s, int i) {
+    // candidates arrive in ascending row order within a lane: strict '>' keeps the earlier row on ties
+    if (!(s > t.s[FR_TOPK - 1])) return;
+    int p = FR_TOPK - 1;
+#pragma unroll
+    for (int k = FR_TOPK - 2; k >= 0; --k) {
+        if (s > t.s[k]) { t.s[k + 1] = t.s[k]; t.i[k + 1] = t.i[k]; p = k; }
+    }
+    t.s[p] = s; t.i[p] = i;
+}
+
+__global__ __launch_bounds__(256) void gallery_scan_f16(const float* __restrict__ Q, const half_t* __restrict__ G,
+                                                        int F, int64_t N, float* __restrict__ ws_score,
+                                                        int* __restrict__ ws_idx) {
+    extern __shared__ __attribute__((aligned(16))) half_t qh[];       // [QG16*32][520] halves (row pad 16 B)
+    constexpr int QP = GD + 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q0 = blockIdx.y * (QG16 * 32);
+    for (int e = tid; e < QG16 * 32 * (GD / 4); e += 256) {
+        const int r = e / (GD / 4), c = e - r * (GD / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q0 + r < F) v = *reinterpret_cast<const float4*>(Q + (int64_t)(q0 + r) * GD + c * 4);
+        half4 h = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+        *reinterpret_cast<half4*>(qh + r * QP + c * 4) = h;
+    }
+    __syncthreads();
+    const int r = lane & 31, h = lane >> 5;
+    Top4 top[QG16];
+#pragma unroll
+    for (int g = 0; g < QG16; ++g)
+#pragma unroll
+        for (int k = 0; k < FR_TOPK; ++k) { top[g].s[k] = -INFINITY; top[g].i[k] = -1; }
+    const int64_t ntiles = (N + 31) / 32;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
+        const int64_t row = t * 32 + r;
+        const bool ok = row < N;
+        const half_t* gp = G + (ok ? row : 0) * GD + 8 * h;
+        float16v acc[QG16];
+#pragma unroll
+        for (int g = 0; g < QG16; ++g)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+#pragma unroll 4
+        for (int kk = 0; kk < GD / 16; ++kk) {
+            half8 a = *reinterpret_cast<const half8*>(gp + kk * 16);
+            if (!ok) a = half8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int g = 0; g < QG16; ++g) {
+                const half8 b = *reinterpret_cast<const half8*>(qh + (g * 32 + r) * QP + kk * 16 + 8 * h);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[g], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < QG16; ++g)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int64_t gi = t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (gi < N) top4_insert(top[g], acc[g][reg], (int)gi);
+            }
+    }
+    // every (block, wave, half) writes its candidates; the re-rank kernel merges them
+    const int slots = gridDim.x * 8;                               // candidate lists per query
+    const int slot = (blockIdx.x * 4 + wave) * 2 + h;
+#pragma unroll
+    for (int g = 0; g < QG16; ++g) {
+        const int q = q0 + g * 32 + r;
+        if (q < F) {
+#pragma unroll
+            for (int k = 0; k < FR_TOPK; ++k) {
+                ws_score[((int64_t)q * slots + slot) * FR_TOPK + k] = top[g].s[k];
+                ws_idx[((int64_t)q * slots + slot) * FR_TOPK + k] = top[g].i[k];
+            }
+        }
+    }
+}
+
+// one wave per query: merge the candidate lists (f16 scores), keep the best FR_TOPK, re-score them in f32
+__global__ __launch_bounds__(64) void gallery_rerank(const float* __restrict__ Q, const float* __restrict__ G32,
+                                                     const float* __restrict__ ws_score, const int* __restrict__ ws_idx,
+                                                     int F, int ncand, int64_t row_offset, int64_t* __restrict__ out_idx,
+                                                     float* __restrict__ out_score) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    float bs[FR_TOPK]; int bi[FR_TOPK];
+#pragma unroll
+    for (int k = 0; k < FR_TOPK; ++k) { bs[k] = -INFINITY; bi[k] = -1; }
+    // FR_TOPK rounds of wave-wide argmax over the candidates (ties -> lowest row), removing the winner each time
+    for (int round = 0; round < FR_TOPK; ++round) {
+        float ms = -INFINITY; int mi = 0x7fffffff;
+        for (int c = lane; c < ncand; c += 64) {
+            const float s = ws_score[(int64_t)q * ncand + c];
+            const int i = ws_idx[(int64_t)q * ncand + c];
+            bool taken = i < 0;
+#pragma unroll
+            for (int k = 0; k < FR_TOPK; ++k) taken |= (k < round && bi[k] == i);
+            if (!taken && (s > ms || (s == ms && i < mi))) { ms = s; mi = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float os = __shfl_xor(ms, o, 64); const int oi = __shfl_xor(mi, o, 64);
+            if (os > ms || (os == ms && oi < mi)) { ms = os; mi = oi; }
+        }
+        bs[round] = ms; bi[round] = (mi == 0x7fffffff) ? -1 : mi;
+    }
+    float best = -INFINITY; int besti = -1;
+#pragma unroll
+    for (int k = 0; k < FR_TOPK; ++k) {
+        if (bi[k] < 0) continue;
+        float s = bs[k];
+        if (G32) {                                                 // exact f32 dot
+            const float* g = G32 + (int64_t)bi[k] * GD;
+            const float* qq = Q + (int64_t)q * GD;
+            float p = 0.f;
+            for (int c = lane * 4; c < GD; c += 256) {
+                const float4 a = *reinterpret_cast<const float4*>(qq + c), b = *reinterpret_cast<const float4*>(g + c);
+                p += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+            }
+            s = wave_sum(p);
+        }
+        if (s > best || (s == best && bi[k] < besti)) { best = s; besti = bi[k]; }
+    }
+    if (lane == 0) {
+        if (besti < 0 || !(best > -1.0f)) { out_idx[q] = -1; out_score[q] = -1.0f; }
+        else { out_idx[q] = besti + row_offset; out_score[q] = best; }
+    }
+}
+
+static int scan16_blocks(int64_t N) {
+    int64_t b = ((N + 31) / 32 + 3) / 4;
+    if (b < 1) b = 1;
+    if (b > 512) b = 512;
+    return (int)b;
+}
+
+extern "C" size_t fr_gallery_match_f16_workspace(int F, int64_t N) {
+    return (size_t)(F > 0 ? F : 1) * scan16_blocks(N) * 8 * FR_TOPK * 8 + 256;
+}
+
+extern "C" int fr_gallery_match_f16(const float* Q, const void* G16, const float* G32, int F, int64_t N, int D,
+                                    int64_t row_offset, int64_t* out_idx, float* out_score, void* workspace,
+                                    size_t workspace_bytes, fr_stream_t stream) {
+    FR_REQUIRE(D == GD, "fr_gallery_match_f16: D must be %d (got %d)", GD, D);
+    FR_REQUIRE(F >= 0 && N >= 0 && N < (1ll << 31), "fr_gallery_match_f16: bad size");
+    if (F == 0) return FR_OK;
+    FR_REQUIRE(Q && out_idx && out_score && (G16 || N == 0), "fr_gallery_match_f16: null pointer");
+    FR_REQUIRE(workspace && workspace_bytes >= fr_gallery_match_f16_workspace(F, N), "fr_gallery_match_f16: workspace too small");
+    hipStream_t s = fr_stream(stream);
+    const int nblk = scan16_blocks(N), ncand = nblk * 8 * FR_TOPK;
+    float* ws_score = reinterpret_cast<float*>(workspace);
+    int* ws_idx = reinterpret_cast<int*>(ws_score + (size_t)F * ncand);
+    const size_t lds = (size_t)QG16 * 32 * (GD + 8) * sizeof(half_t);            // 133 KB
+    static bool done = false;
+    if (!done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gallery_scan_f16), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) { fr_set_error("fr_gallery_match_f16: cannot raise dynamic LDS"); return FR_E_LAUNCH; }
+        done = true;
+    }
+    dim3 grid(nblk, (F + QG16 * 32 - 1) / (QG16 * 32));
+    gallery_scan_f16<<<grid, 256, lds, s>>>(Q, reinterpret_cast<const half_t*>(G16), F, N, ws_score, ws_idx);
+    FR_CHECK_LAUNCH("gallery_scan_f16");
+    gallery_rerank<<<F, 64, 0, s>>>(Q, G32, ws_score, ws_idx, F, ncand, row_offset, out_idx, out_score);
+    FR_CHECK_LAUNCH("gallery_rerank");
     return FR_OK;
 }

@@ -17,8 +17,12 @@ DIM = 512
 class GalleryMatcher:
     """``G[N,512]`` float32 unit rows on the device + the id table."""
 
-    def __init__(self, device="cuda:0"):
+    def __init__(self, device="cuda:0", f16_scan=False):
+        """``f16_scan``: keep an f16 copy of the rows and scan it on the f16 matrix cores, then re-score the
+        top-4 rows per query exactly in f32 (large galleries / many queries); the f32 rows are kept."""
         _lib.require_gpu()
+        self.f16_scan = f16_scan
+        self.G16 = None
         self.lib = _lib.load()
         self.device = torch.device(device)
         self.ids = []
@@ -42,6 +46,11 @@ class GalleryMatcher:
             rows = out
         self.ids = list(ids)
         self.G = rows
+        self.G16 = None
+        if self.f16_scan and rows.shape[0]:
+            self.G16 = torch.empty(rows.shape, dtype=torch.float16, device=self.device)
+            with torch.cuda.device(self.device):
+                self.lib.fr_f32_to_f16(_lib.ptr(rows), _lib.ptr(self.G16), rows.numel(), _lib.stream_ptr())
 
     def _workspace(self, F):
         need = self.lib.fr_gallery_match_workspace(F, self.G.shape[0])
@@ -64,6 +73,14 @@ class GalleryMatcher:
                 Qn = torch.empty_like(Q)
                 self.lib.fr_l2norm_rows_f32(_lib.ptr(Q), _lib.ptr(Qn), F, DIM, s)
                 Q = Qn
+            if self.G16 is not None:
+                need = self.lib.fr_gallery_match_f16_workspace(F, self.G.shape[0])
+                if self._ws is None or self._ws.numel() < need:
+                    self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                self.lib.fr_gallery_match_f16(_lib.ptr(Q), _lib.ptr(self.G16), _lib.ptr(self.G), F, self.G.shape[0], DIM,
+                                              row_offset, _lib.ptr(idx), _lib.ptr(score), _lib.ptr(self._ws),
+                                              self._ws.numel(), s)
+                return idx, score
             ws = self._workspace(F)
             self.lib.fr_gallery_match_f32(_lib.ptr(Q), _lib.ptr(self.G), F, self.G.shape[0], DIM, row_offset,
                                           _lib.ptr(idx), _lib.ptr(score), _lib.ptr(ws), ws.numel(), s)

@@ -48,6 +48,14 @@ size_t fr_gallery_match_workspace(int F, int64_t N);
 int fr_gallery_match_f32(const float* Q, const float* G, int F, int64_t N, int D,
                          int64_t row_offset, int64_t* out_idx, float* out_score,
                          void* workspace, size_t workspace_bytes, fr_stream_t stream);
+/* f16 gallery (1 M .. 10 M rows): coarse scan on the f16 matrix cores keeps the top FR_TOPK rows per
+ * query, which are then re-scored exactly in f32 against G32 (may be NULL: scores then come from the
+ * f16 scan) and picked by max score / lowest row.  G16: f16 [N,512] (fr_f32_to_f16 of the unit rows). */
+#define FR_TOPK 4
+size_t fr_gallery_match_f16_workspace(int F, int64_t N);
+int fr_gallery_match_f16(const float* Q, const void* G16, const float* G32, int F, int64_t N, int D,
+                         int64_t row_offset, int64_t* out_idx, float* out_score,
+                         void* workspace, size_t workspace_bytes, fr_stream_t stream);
 /* f32 -> f16 row conversion for building the device-resident gallery (infrenceServer.py:271) */
 int fr_f32_to_f16(const float* x, void* out, int64_t n, fr_stream_t stream);
 /* a-8  known = best_id and best >= thr  (infrenceServer.py:545; peopleCount.py:876-882):

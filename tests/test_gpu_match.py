@@ -80,3 +80,34 @@ def test_full_size_property_planted_rows(matcher):
         idx, score = matcher.match_device(Q)
         assert torch.equal(idx, rows)
         assert float(score.min()) > 0.8
+
+
+@pytest.mark.parametrize("N,F", [(1, 1), (33, 5), (4097, 130), (100_000, 256)])
+def test_f16_scan_with_f32_rerank_matches_f32_oracle(N, F):
+    """f16 coarse scan + exact f32 re-rank must give the SAME ids as the f32 oracle (incl. duplicate rows)."""
+    from facerecognition_infrenceengine_amd.gallery import GalleryMatcher
+    rng = np.random.default_rng(N * 7 + F)
+    G = rng.standard_normal((N, 512)).astype(np.float32); G /= np.linalg.norm(G, axis=1, keepdims=True)
+    Q = rng.standard_normal((F, 512)).astype(np.float32); Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    if N > 3:
+        G[N - 1] = Q[0]; G[N // 2] = Q[0]
+        Q[1 % F] = G[N // 3] + 0.01 * rng.standard_normal(512).astype(np.float32)      # near-duplicate of one row
+    m = GalleryMatcher("cuda:0", f16_scan=True)
+    m.set_rows(list(range(N)), G, normalise=False)
+    idx, score = m.match_device(torch.from_numpy(Q).cuda())
+    oi, os_ = omatch.match_rows_fast(Q, G)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    np.testing.assert_allclose(score.cpu().numpy(), os_, atol=3e-6)                     # scores are the f32 re-scores
+
+
+def test_f16_scan_full_size_planted_rows():
+    from facerecognition_infrenceengine_amd.gallery import GalleryMatcher
+    g = torch.Generator(device="cuda").manual_seed(3)
+    N = 1_000_000
+    G = torch.randn((N, 512), generator=g, device="cuda"); G /= G.norm(dim=1, keepdim=True)
+    rows = torch.randperm(N, generator=g, device="cuda")[:2048]                        # 8 ranks x 256 gathered queries
+    Q = G[rows] + 0.02 * torch.randn((2048, 512), generator=g, device="cuda")
+    m = GalleryMatcher("cuda:0", f16_scan=True)
+    m.set_rows(range(N), G, normalise=False)
+    idx, score = m.match_device(Q)
+    assert torch.equal(idx, rows) and float(score.min()) > 0.8
