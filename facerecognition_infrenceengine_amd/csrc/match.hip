@@ -322,19 +322,22 @@ extern "C" int fr_mean_rows_f32(const float* x, int K, int D, float* out, fr_str
 // query and 16 rows per tile and keeps its top-FR_TOPK candidates locally.  The per-block candidates are then
 // merged and RE-SCORED EXACTLY in f32 against the f32 rows; the final pick is max f32 score, lowest row on
 // ties - the reference's rule - so f16 rounding can only matter if the true winner fell out of the f16 top-4.
-#define QG16 4            // query groups (of 32) per pass: 128 queries share one sweep of the gallery
+#define QG16 2            // query groups (of 32) per pass: 64 queries share one sweep; 66 KB LDS -> 2 blocks/CU
 
 struct Top4 { float s[FR_TOPK]; int i[FR_TOPK]; };
 
 __device__ __forceinline__ void top4_insert(Top4& t, float s, int i) {
-    // candidates arrive in ascending row order within a lane: strict '>' keeps the earlier row on ties
+    // candidates arrive in ascending row order within a lane: strict '>' keeps the earlier row on ties.
+    // Static indices only (a runtime-indexed store would push the lists to scratch memory).
     if (!(s > t.s[FR_TOPK - 1])) return;
-    int p = FR_TOPK - 1;
+    t.s[FR_TOPK - 1] = s; t.i[FR_TOPK - 1] = i;
 #pragma unroll
-    for (int k = FR_TOPK - 2; k >= 0; --k) {
-        if (s > t.s[k]) { t.s[k + 1] = t.s[k]; t.i[k + 1] = t.i[k]; p = k; }
+    for (int k = FR_TOPK - 1; k > 0; --k) {
+        const bool up = t.s[k] > t.s[k - 1];
+        const float hs = up ? t.s[k] : t.s[k - 1], ls = up ? t.s[k - 1] : t.s[k];
+        const int hi = up ? t.i[k] : t.i[k - 1], li = up ? t.i[k - 1] : t.i[k];
+        t.s[k - 1] = hs; t.s[k] = ls; t.i[k - 1] = hi; t.i[k] = li;
     }
-    t.s[p] = s; t.i[p] = i;
 }
 
 __global__ __launch_bounds__(256) void gallery_scan_f16(const float* __restrict__ Q, const half_t* __restrict__ G,
@@ -368,14 +371,24 @@ __global__ __launch_bounds__(256) void gallery_scan_f16(const float* __restrict_
         for (int g = 0; g < QG16; ++g)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
-#pragma unroll 4
-        for (int kk = 0; kk < GD / 16; ++kk) {
-            half8 a = *reinterpret_cast<const half8*>(gp + kk * 16);
-            if (!ok) a = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        // the tile's 32 x 1 KB rows are fetched as two bursts of 16 independent 16-byte loads per lane
+        // (memory-level parallelism: a dependent load per MFMA step left the scan latency-bound at 0.8 TB/s)
 #pragma unroll
-            for (int g = 0; g < QG16; ++g) {
-                const half8 b = *reinterpret_cast<const half8*>(qh + (g * 32 + r) * QP + kk * 16 + 8 * h);
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[g], 0, 0, 0);
+        for (int half = 0; half < 2; ++half) {
+            half8 a[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                a[u] = *reinterpret_cast<const half8*>(gp + (half * 16 + u) * 16);
+                if (!ok) a[u] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int kk = half * 16 + u;
+#pragma unroll
+                for (int g = 0; g < QG16; ++g) {
+                    const half8 b = *reinterpret_cast<const half8*>(qh + (g * 32 + r) * QP + kk * 16 + 8 * h);
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u], b, acc[g], 0, 0, 0);
+                }
             }
         }
 #pragma unroll
@@ -475,7 +488,7 @@ extern "C" int fr_gallery_match_f16(const float* Q, const void* G16, const float
     const int nblk = scan16_blocks(N), ncand = nblk * 8 * FR_TOPK;
     float* ws_score = reinterpret_cast<float*>(workspace);
     int* ws_idx = reinterpret_cast<int*>(ws_score + (size_t)F * ncand);
-    const size_t lds = (size_t)QG16 * 32 * (GD + 8) * sizeof(half_t);            // 133 KB
+    const size_t lds = (size_t)QG16 * 32 * (GD + 8) * sizeof(half_t);            // 66.5 KB
     static bool done = false;
     if (!done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gallery_scan_f16), hipFuncAttributeMaxDynamicSharedMemorySize,
