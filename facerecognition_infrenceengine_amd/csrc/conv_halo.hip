@@ -24,7 +24,6 @@ struct HaloP {
     int TH, tiles_per_img;      // output rows per tile, H / TH
     unsigned xbytes, wbytes;
     unsigned long long* stamps; // diagnostic build only (FR_DBG_STAMPS=<device ptr>): per-wave segment cycle sums
-    int dbg;                    // development ablations (timing only): 1 no loads in loop, 2 no MFMA, 4 no barrier, 8 no LDS reads
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -69,7 +68,6 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
     half_t* xs = lds;                                 // [NXBUF][XROWS][HK]
     half_t* ws = lds + NXBUF * XROWS * HK;            // [2][BN][HK]
 
-    if (p.dbg & 16) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: LDS-DMA bases stay in SGPRs
     const int wn = wave % WN, wp = wave / WN;
@@ -217,7 +215,6 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
     // W(0) and the first halo must be visible before the first fragment reads
     if (nq > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWI) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (p.dbg & 64) return;
     read_frags(a0, b0, 0, 0, 0, 0, 0);
     int tap = 0, c = 0, toff = 0, kw = 0, kh = 0;
     bool x_inflight = false;               // a halo was issued at the previous mid-step (after the W loads)
@@ -292,7 +289,6 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
     // as [px][BN] f16 (row pitch + 16 B against bank conflicts) and moved with 16-byte fully coalesced
     // accesses: (A) residual tile global -> LDS, (B) each lane: acc + bias -> PReLU -> + residual -> f16,
     // in place, (C) LDS -> global.  One rounding to f16, as in conv_mfma.hip.
-    if (p.dbg & 32) { if (acc[0][0][0] == 12345.f) p.y[0] = (half_t)1.f; return; }
     constexpr int OP = BN + 8;                         // row pitch in halves
     constexpr int CPR = BN / 8;                        // 16-B chunks per row
     half_t* ot = lds;
@@ -389,7 +385,6 @@ int fr_conv_halo_try(const fr_conv_args* a, hipStream_t s) {
     p.xbytes = (unsigned)((int64_t)a->B * a->H * a->W * a->Cin * 2);
     p.wbytes = (unsigned)((int64_t)a->Cout * 9 * a->Cin * 2);
     { static long long sp = -1; if (sp < 0) { const char* e = getenv("FR_DBG_STAMPS"); sp = e ? strtoll(e, nullptr, 0) : 0; } p.stamps = (unsigned long long*)sp; }
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("FR_CONV_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     int rc;
     if (a->H == 56) rc = launch_halo<1, 14, 384, 1, 4>(p, s);
     else if (a->H == 112) rc = launch_halo<1, 14, 512, 1, 4>(p, s);

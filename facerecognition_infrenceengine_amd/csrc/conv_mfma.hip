@@ -24,7 +24,6 @@ struct ConvP {
     const float* bias; const float* slope; const half_t* res; float* partial;
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, bias_mode, splitk;
     int M, K, nk;            // M = B*Ho*Wo, K = row length of w (halves), nk = K / 64
-    int dbg;                 // development ablations (timing only): 1 = no loads in loop, 2 = no MFMA, 4 = no barrier
     unsigned xbytes, wbytes;
 };
 
@@ -355,7 +354,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pipe(ConvP p) {
 
     const int fr = lane & 15, fq = lane >> 4;
     const int rdoff = fr * PK + ((fq ^ ((0x1320 >> (4 * ((fr >> 2) & 3))) & 3)) << 3);   // halves, within a 16-row tile
-    if (p.dbg & 16) return;
 #pragma unroll
     for (int d = 0; d < PNS - 1; ++d)
         if (ks + d < ke) issue(ks + d);
@@ -364,35 +362,21 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pipe(ConvP p) {
         if (rem >= PNS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (PNS - 2)) : "memory");
         else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(p.dbg & 4)) __builtin_amdgcn_s_barrier();
-        if (s + PNS - 1 < ke && !(p.dbg & 1)) issue(s + PNS - 1);
+        __builtin_amdgcn_s_barrier();
+        if (s + PNS - 1 < ke) issue(s + PNS - 1);
         const half_t* wl = lds + ((s - ks) % PNS) * STAGE + (wc * 64) * PK;
         const half_t* xl = lds + ((s - ks) % PNS) * STAGE + BN * PK + (wp * 64) * PK;
         half8 a[4], b[4];
-        if (p.dbg & 8) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] = half8{1, 0, 0, 0, 0, 0, 0, 0}; b[i] = a[i]; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = *reinterpret_cast<const half8*>(wl + i * 16 * PK + rdoff);
-                b[i] = *reinterpret_cast<const half8*>(xl + i * 16 * PK + rdoff);
-            }
+        for (int i = 0; i < 4; ++i) {
+            a[i] = *reinterpret_cast<const half8*>(wl + i * 16 * PK + rdoff);
+            b[i] = *reinterpret_cast<const half8*>(xl + i * 16 * PK + rdoff);
         }
-        if (p.dbg & 2) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(a[i]), "v"(b[i]));
-        } else {
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-    }
-    if (p.dbg & 32) {
-        if (acc[0][0][0] == 12345.678f) p.y[0] = (half_t)1.f;      // keep the accumulators alive
-        return;
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     conv_epilogue<WN>(p, acc, cout0, m0, wc, wp, fr, fq);
 #endif
@@ -449,7 +433,6 @@ extern "C" int fr_conv_nhwc_f16(const fr_conv_args* a, fr_stream_t stream) {
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.KH = a->KH; p.KW = a->KW;
     p.stride = a->stride; p.pad = a->pad; p.Ho = a->Ho; p.Wo = a->Wo; p.bias_mode = a->bias_mode;
     p.splitk = a->splitk > 1 ? a->splitk : 1;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("FR_CONV_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     FR_REQUIRE(p.splitk == 1 || p.partial, "fr_conv_nhwc_f16: splitk > 1 needs out_f32_partial");
     int64_t M = (int64_t)a->B * a->Ho * a->Wo;
     int64_t xbytes = (int64_t)a->B * a->H * a->W * a->Cin * 2;

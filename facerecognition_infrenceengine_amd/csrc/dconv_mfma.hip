@@ -25,7 +25,6 @@ struct DcArgs {
     int Ho, Wo;           // conv output extent (H-KH+1, W-KW+1)
     int regions_x, regions_y;
     const uint8_t* frames; int FH, FW;   // SRC == 1: u8 BGR frames [B,FH,FW,3], resized on the fly
-    int dbg;                             // development ablation (timing only): 1 = skip the MFMAs
 };
 
 // POOL: 0 none | 1 fused 2x2/s2 ceil max pool in registers (needs RW % 16 == 0) | 2 fused PKxPK/s2 ceil max
@@ -432,9 +431,7 @@ extern "C" int fr_dconv_mfma_f32(int layer, const float* x, const float* w, cons
                                  const uint8_t* frames, int FH, int FW, fr_stream_t stream) {
     FR_REQUIRE(w && bias && y && B > 0 && H > 0 && W > 0, "fr_dconv_mfma_f32: bad argument");
     FR_REQUIRE((layer == 0) ? (frames && FH > 0 && FW > 0) : (x != nullptr), "fr_dconv_mfma_f32: no input");
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("FR_DET_DBG"); dbg = e ? atoi(e) : 0; }
-    DcArgs a{x, w, bias, slope, y, head_w, head_b, B, H, W, 0, 0, 0, 0, frames, FH, FW, dbg};
+    DcArgs a{x, w, bias, slope, y, head_w, head_b, B, H, W, 0, 0, 0, 0, frames, FH, FW};
     hipStream_t s = fr_stream(stream);
     int rc = FR_OK;
     switch (layer) {
