@@ -31,7 +31,7 @@ struct DcArgs {
 // pool through an LDS conv-output tile (regions step by RSY x RSX conv pixels, RH x RW computed per region).
 // RPB: regions per block along x (weights staged once per block).  SRC 1: input = bilinear resize of u8 frames.
 template <int CIN, int COUT, int KH, int KW, int RH, int RW, int G, int NTB, int WN, int TG, int POOL, int PK,
-          int RSY, int RSX, int NHEAD, int RPB, int SRC>
+          int RSY, int RSX, int NHEAD, int RPB, int SRC, int NW = 4>
 struct DcCfg {
     static constexpr int CINP = (CIN + 3) / 4 * 4;
     static constexpr int CINS = CINP + 1;
@@ -40,7 +40,8 @@ struct DcCfg {
     static constexpr int CP = NTB * 16 + ((NTB % 2 == 0) ? 16 : 0);
     static constexpr int NTAPS = KH * KW;
     static constexpr int NSTAGE = NTAPS / TG;
-    static constexpr int WM = 4 / WN, NT = NTB / WN;
+    static constexpr int WM = NW / WN, NT = NTB / WN;
+    static constexpr int NTHR = NW * 64;
     static constexpr int NPIX = G * RH * RW;
     static constexpr int TP = (NPIX + 15) / 16;
     static constexpr int PT = (TP + WM - 1) / WM;
@@ -51,7 +52,7 @@ struct DcCfg {
     static constexpr int LDS_FLOATS = W_OFF + TG * CINP * CP;
     static_assert(NTAPS % TG == 0, "TG must divide the tap count");
     static_assert(NTB % WN == 0 && (WN == 1 || WN == 2 || WN == 4), "bad wave split");
-    static_assert(POOL != 1 || (RW % 16 == 0 && RH % 2 == 0 && G == 1 && WN == 1 && (RH * RW / 16) % 4 == 0), "pool layout");
+    static_assert(POOL != 1 || (RW % 16 == 0 && RH % 2 == 0 && G == 1 && WN == 1 && (RH * RW / 16) % NW == 0), "pool layout");
     static_assert(RPB == 1 || NSTAGE == 1, "multi-item blocks need resident weights");
     static_assert(CIN % 4 == 0 || SRC == 1, "f32 inputs are read as float4: pad channels to a multiple of 4");
     static_assert(SRC == 0 || CIN == 3, "fused resize feeds a 3-channel layer");
@@ -75,9 +76,9 @@ __device__ __forceinline__ float dbilerp(float p00, float p01, float p10, float 
 }
 
 template <int CIN, int COUT, int KH, int KW, int RH, int RW, int G, int NTB, int WN, int TG, int POOL, int PK,
-          int RSY, int RSX, int NHEAD, int RPB, int SRC>
-__global__ __launch_bounds__(256) void dconv_mfma(DcArgs a) {
-    using C = DcCfg<CIN, COUT, KH, KW, RH, RW, G, NTB, WN, TG, POOL, PK, RSY, RSX, NHEAD, RPB, SRC>;
+          int RSY, int RSX, int NHEAD, int RPB, int SRC, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
+    using C = DcCfg<CIN, COUT, KH, KW, RH, RW, G, NTB, WN, TG, POOL, PK, RSY, RSX, NHEAD, RPB, SRC, NW>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xin = lds;
     float* wl = lds + C::W_OFF;
@@ -94,47 +95,60 @@ __global__ __launch_bounds__(256) void dconv_mfma(DcArgs a) {
     auto stage_weights = [&](int st) {
         const float4v* src4 = reinterpret_cast<const float4v*>(wsrc + (int64_t)st * TG * C::CINP * C::CP);
         float4v* dst4 = reinterpret_cast<float4v*>(wl);
-        for (int e = tid; e < TG * C::CINP * C::CP / 4; e += 256) dst4[e] = src4[e];
+        for (int e = tid; e < TG * C::CINP * C::CP / 4; e += C::NTHR) dst4[e] = src4[e];
     };
 
     // ---- input tile: global -> registers (issued early, lands under the previous item's MFMAs) -> LDS
     constexpr int C4 = C::CINP / 4;
     constexpr int NLOAD = SRC == 1 ? C::IH * C::IW : G * C::IH * C::IW * C4;     // float4 slots of one tile
-    constexpr int NPF = (NLOAD + 255) / 256;
+    constexpr int NPF = (NLOAD + C::NTHR - 1) / C::NTHR;
     float4v pf[NPF];
+    // per-slot constants (tile-relative pixel, channel group, LDS offset) decoded ONCE, not per tile
+    int sl_yx[NPF], sl_gc[NPF], sl_lds[NPF];
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+        const int e = tid + u * C::NTHR;
+        int iy = 0, ix = 0, g = 0, c4 = 0, l = -1;
+        if (e < NLOAD) {
+            if constexpr (SRC == 1) {
+                iy = e / C::IW; ix = e - iy * C::IW;
+                l = e * C::CINS;
+            } else {
+                c4 = e % C4;
+                const int pix_g = e / C4;
+                g = pix_g / (C::IH * C::IW);
+                const int pix = pix_g - g * (C::IH * C::IW);
+                iy = pix / C::IW; ix = pix - iy * C::IW;
+                l = g * C::IMG + pix * C::CINS + c4 * 4;
+            }
+        }
+        sl_yx[u] = (iy << 16) | ix; sl_gc[u] = (g << 16) | c4; sl_lds[u] = l;
+    }
     auto load_tile = [&](int item) {
         const int zz = item / per_img, rem = item - zz * per_img;
         const int ry = rem / a.regions_x, rx = rem - ry * a.regions_x;
         const int y0 = ry * RSY, x0 = rx * RSX, img0 = zz * G;
 #pragma unroll
         for (int u = 0; u < NPF; ++u) {
-            const int e = tid + u * 256;
             float4v v = {0.f, 0.f, 0.f, 0.f};
-            if (e < NLOAD) {
+            const int yy = y0 + (sl_yx[u] >> 16), xx = x0 + (sl_yx[u] & 0xffff);
+            const int n = img0 + (sl_gc[u] >> 16);
+            if (sl_lds[u] >= 0 && n < a.B && yy < a.H && xx < a.W) {
                 if constexpr (SRC == 1) {
-                    const int iy = e / C::IW, ix = e - iy * C::IW;
-                    const int n = img0, yy = y0 + iy, xx = x0 + ix;
-                    if (n < a.B && yy < a.H && xx < a.W) {
-                        const float ryr = (float)a.FH / (float)a.H, rxr = (float)a.FW / (float)a.W;
-                        const DLerp ly = dlerp_coord(yy, ryr, a.FH), lx = dlerp_coord(xx, rxr, a.FW);
-                        const uint8_t* f = a.frames + (int64_t)n * a.FH * a.FW * 3;
-                        const uint8_t* r0 = f + (int64_t)ly.i0 * a.FW * 3;
-                        const uint8_t* r1 = f + (int64_t)ly.i1 * a.FW * 3;
+                    const float ryr = (float)a.FH / (float)a.H, rxr = (float)a.FW / (float)a.W;
+                    const DLerp ly = dlerp_coord(yy, ryr, a.FH), lx = dlerp_coord(xx, rxr, a.FW);
+                    const uint8_t* f = a.frames + (int64_t)n * a.FH * a.FW * 3;
+                    const uint8_t* r0 = f + (int64_t)ly.i0 * a.FW * 3;
+                    const uint8_t* r1 = f + (int64_t)ly.i1 * a.FW * 3;
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const int ci = 2 - c;                   // BGR -> RGB
-                            const float sv = dbilerp((float)r0[lx.i0 * 3 + ci], (float)r0[lx.i1 * 3 + ci],
-                                                     (float)r1[lx.i0 * 3 + ci], (float)r1[lx.i1 * 3 + ci], lx.w, ly.w);
-                            v[c] = (sv - 127.5f) * 0.0078125f;
-                        }
+                    for (int c = 0; c < 3; ++c) {
+                        const int ci = 2 - c;                   // BGR -> RGB
+                        const float sv = dbilerp((float)r0[lx.i0 * 3 + ci], (float)r0[lx.i1 * 3 + ci],
+                                                 (float)r1[lx.i0 * 3 + ci], (float)r1[lx.i1 * 3 + ci], lx.w, ly.w);
+                        v[c] = (sv - 127.5f) * 0.0078125f;
                     }
                 } else {
-                    const int c4 = e % C4, pix_g = e / C4;
-                    const int g = pix_g / (C::IH * C::IW), pix = pix_g - g * (C::IH * C::IW);
-                    const int iy = pix / C::IW, ix = pix - iy * C::IW;
-                    const int n = img0 + g, yy = y0 + iy, xx = x0 + ix;
-                    if (n < a.B && yy < a.H && xx < a.W)
-                        v = *reinterpret_cast<const float4v*>(a.x + (((int64_t)n * a.H + yy) * a.W + xx) * CIN + c4 * 4);
+                    v = *reinterpret_cast<const float4v*>(a.x + (((int64_t)n * a.H + yy) * a.W + xx) * CIN + (sl_gc[u] & 0xffff) * 4);
                 }
             }
             pf[u] = v;
@@ -143,15 +157,8 @@ __global__ __launch_bounds__(256) void dconv_mfma(DcArgs a) {
     auto store_tile = [&]() {
 #pragma unroll
         for (int u = 0; u < NPF; ++u) {
-            const int e = tid + u * 256;
-            if (e < NLOAD) {
-                float* d;
-                if constexpr (SRC == 1) d = xin + e * C::CINS;
-                else {
-                    const int c4 = e % C4, pix_g = e / C4;
-                    const int g = pix_g / (C::IH * C::IW), pix = pix_g - g * (C::IH * C::IW);
-                    d = xin + g * C::IMG + pix * C::CINS + c4 * 4;
-                }
+            if (sl_lds[u] >= 0) {
+                float* d = xin + sl_lds[u];
                 d[0] = pf[u][0]; d[1] = pf[u][1]; d[2] = pf[u][2]; d[3] = pf[u][3];
             }
         }
@@ -213,24 +220,37 @@ __global__ __launch_bounds__(256) void dconv_mfma(DcArgs a) {
                 stage_weights(st);
             }
             __syncthreads();
-#pragma unroll
-            for (int tl = 0; tl < TG; ++tl) {
+            // operands of k step s+1 are read before the MFMAs of step s are issued (the compiler's own order
+            // issues each step's ds_reads right in front of their first use and exposes the LDS latency)
+            constexpr int KSTEPS = TG * (C::CINP / 4);
+            auto rd = [&](int ks, float (&av)[C::NT], float (&bv)[C::PT]) {
+                const int tl = ks / (C::CINP / 4), c4 = ks - tl * (C::CINP / 4);
                 const int tap = st * TG + tl;
                 const int kh = tap / KW, kw = tap - kh * KW;
                 const int toff = (kh * C::IW + kw) * C::CINS;
                 const float* wt = wl + (tl * C::CINP + kq) * C::CP + wn * C::NT * 16 + li;
 #pragma unroll
-                for (int c4 = 0; c4 < C::CINP / 4; ++c4) {
-                    float av[C::NT], bv[C::PT];
+                for (int i = 0; i < C::NT; ++i) av[i] = wt[c4 * 4 * C::CP + i * 16];
 #pragma unroll
-                    for (int i = 0; i < C::NT; ++i) av[i] = wt[c4 * 4 * C::CP + i * 16];
+                for (int t = 0; t < C::PT; ++t) bv[t] = xin[base[t] + toff + c4 * 4];
+            };
+            float av0[C::NT], bv0[C::PT], av1[C::NT], bv1[C::PT];
+            rd(0, av0, bv0);
 #pragma unroll
-                    for (int t = 0; t < C::PT; ++t) bv[t] = xin[base[t] + toff + c4 * 4];
+            for (int ks = 0; ks < KSTEPS; ks += 2) {
+                if (ks + 1 < KSTEPS) rd(ks + 1, av1, bv1);
+#pragma unroll
+                for (int i = 0; i < C::NT; ++i)
+#pragma unroll
+                    for (int t = 0; t < C::PT; ++t)
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[i], bv0[t], acc[i][t], 0, 0, 0);
+                if (ks + 1 < KSTEPS) {
+                    if (ks + 2 < KSTEPS) rd(ks + 2, av0, bv0);
 #pragma unroll
                     for (int i = 0; i < C::NT; ++i)
 #pragma unroll
                         for (int t = 0; t < C::PT; ++t)
-                            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[t], acc[i][t], 0, 0, 0);
+                            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[i], bv1[t], acc[i][t], 0, 0, 0);
                 }
             }
         }
@@ -307,7 +327,7 @@ __global__ __launch_bounds__(256) void dconv_mfma(DcArgs a) {
             const int PW = (a.Wo - PK + 1) / 2 + 1 - ((((a.Wo - PK + 1) / 2) * 2 >= a.Wo) ? 1 : 0);
             constexpr int PRH = RSY / 2, PRW = RSX / 2;     // pooled rows / cols owned by one region
             constexpr int CG = NTB * 16;
-            for (int e = tid; e < G * PRH * PRW * CG; e += 256) {
+            for (int e = tid; e < G * PRH * PRW * CG; e += C::NTHR) {
                 const int co = e % CG, pp = e / CG;
                 const int g = pp / (PRH * PRW), q = pp - g * (PRH * PRW);
                 const int pyl = q / PRW, pxl = q - pyl * PRW;
@@ -390,9 +410,9 @@ __global__ __launch_bounds__(256) void dconv_mfma(DcArgs a) {
 }
 
 template <int CIN, int COUT, int KH, int KW, int RH, int RW, int G, int NTB, int WN, int TG, int POOL, int PK,
-          int RSY, int RSX, int NHEAD, int RPB, int SRC>
+          int RSY, int RSX, int NHEAD, int RPB, int SRC, int NW = 4>
 static int launch_dc(const DcArgs& a0, hipStream_t s) {
-    using C = DcCfg<CIN, COUT, KH, KW, RH, RW, G, NTB, WN, TG, POOL, PK, RSY, RSX, NHEAD, RPB, SRC>;
+    using C = DcCfg<CIN, COUT, KH, KW, RH, RW, G, NTB, WN, TG, POOL, PK, RSY, RSX, NHEAD, RPB, SRC, NW>;
     DcArgs a = a0;
     a.Ho = a.H - KH + 1; a.Wo = a.W - KW + 1;
     if constexpr (POOL == 2) {      // regions tile the POOLED output: a region owns RSY/2 x RSX/2 pooled pixels
@@ -409,7 +429,7 @@ static int launch_dc(const DcArgs& a0, hipStream_t s) {
     const int nitems = a.regions_x * a.regions_y * ((a.B + G - 1) / G);
     dim3 grid((nitems + RPB - 1) / RPB, COUTP / (NTB * 16), 1);
     const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
-    auto kern = dconv_mfma<CIN, COUT, KH, KW, RH, RW, G, NTB, WN, TG, POOL, PK, RSY, RSX, NHEAD, RPB, SRC>;
+    auto kern = dconv_mfma<CIN, COUT, KH, KW, RH, RW, G, NTB, WN, TG, POOL, PK, RSY, RSX, NHEAD, RPB, SRC, NW>;
     if (lds > 64 * 1024) {
         static bool done = false;       // attribute is per function; benign race (idempotent)
         if (!done) {
@@ -421,7 +441,7 @@ static int launch_dc(const DcArgs& a0, hipStream_t s) {
             done = true;
         }
     }
-    kern<<<grid, 256, lds, s>>>(a);
+    kern<<<grid, NW * 64, lds, s>>>(a);
     return FR_OK;
 }
 
@@ -439,9 +459,18 @@ extern "C" int fr_dconv_mfma_f32(int layer, const float* x, const float* w, cons
         case 0:  FR_REQUIRE(H >= 3 && W >= 3 && frames, "P1 needs frames and a level of at least 3x3");
                  rc = launch_dc<3, 12, 3, 3, 16, 32, 1, 1, 1, 9, 1, 2, 16, 32, 0, 1, 1>(a, s); break;     // P-Net conv1 (+resize, PReLU, pool)
         case 1:  FR_REQUIRE(H >= 3 && W >= 3, "P2 input too small");
-                 rc = launch_dc<12, 16, 3, 3, 8, 32, 1, 1, 1, 9, 0, 2, 8, 32, 0, 8, 0>(a, s); break;      // P-Net conv2
+                 // small pyramid levels have too few tiles to fill 256 CUs: multi-tile blocks only add latency there
+                 if ((int64_t)((H - 2 + 7) / 8) * ((W - 2 + 31) / 32) * B < 8192)
+                     rc = launch_dc<12, 16, 3, 3, 8, 32, 1, 1, 1, 9, 0, 2, 8, 32, 0, 1, 0>(a, s);
+                 else
+                     rc = launch_dc<12, 16, 3, 3, 8, 32, 1, 1, 1, 9, 0, 2, 8, 32, 0, 8, 0>(a, s);
+                 break;                                                                                   // P-Net conv2
         case 2:  FR_REQUIRE(H >= 3 && W >= 3 && head_w && head_b, "P3 needs head weights");
-                 rc = launch_dc<16, 32, 3, 3, 8, 32, 1, 2, 1, 9, 0, 2, 8, 32, 6, 8, 0>(a, s); break;      // P-Net conv3+heads
+                 if ((int64_t)((H - 2 + 15) / 16) * ((W - 2 + 31) / 32) * B < 4096)
+                     rc = launch_dc<16, 32, 3, 3, 8, 32, 1, 2, 1, 9, 0, 2, 8, 32, 6, 1, 0>(a, s);          // 4 waves, 1 tile
+                 else
+                     rc = launch_dc<16, 32, 3, 3, 16, 32, 1, 2, 1, 9, 0, 2, 16, 32, 6, 4, 0, 8>(a, s);     // 8 waves, 4 tiles
+                 break;                                                                                   // P-Net conv3+heads
         case 10: FR_REQUIRE(H == 24 && W == 24, "R1 expects 24x24");                        // conv1 + 3x3/s2 pool -> 11x11
                  rc = launch_dc<4, 28, 3, 3, 22, 22, 1, 2, 1, 9, 2, 3, 22, 22, 0, 4, 0>(a, s); break;
         case 11: FR_REQUIRE(H == 11 && W == 11, "R2 expects 11x11");                        // conv2 + 3x3/s2 pool -> 4x4
