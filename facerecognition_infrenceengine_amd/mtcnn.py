@@ -126,6 +126,7 @@ class MTCNNHIP:
         self.minsize, self.factor, self.thresholds = minsize, factor, tuple(float(t) for t in thresholds)
         self.cap_scale, self.keep_scale, self.cap_p, self.cap_r, self.cap_o = cap_scale, keep_scale, cap_p, cap_r, cap_o
         assert cap_scale <= 4096 and cap_p <= 1024 and cap_r <= 1024 and cap_o <= 1024
+        self._side = None
         d = self.device
         p, r, o = ({k: v.detach().float().cpu() for k, v in s.items()} for s in (pstate, rstate, ostate))
         self.p1 = _MConv(0, p["conv1.weight"], p["conv1.bias"], p["prelu1.weight"], d)
@@ -229,16 +230,27 @@ class MTCNNHIP:
             assert nlev * self.keep_scale <= 4096, "too many pyramid levels for the merged NMS list"
             cs = self.cap_scale
             lb, ls, lr, lc = self._f32(nlev, N, cs, 4), self._f32(nlev, N, cs), self._f32(nlev, N, cs, 4), self._i32(nlev, N)
+            # Level 0 holds half of the pyramid's pixels; the remaining levels are small launches that cannot fill
+            # 256 CUs on their own, so they run on a second HIP stream beside level 0 (joined before the NMS).
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            side = self._side
+            side.wait_stream(main)
             for li, s in enumerate(scales):
-                head, hc, wc = self.pnet_level(frames, s, trace)
-                nblk = -(-hc * wc // 256)
-                bc = self._i32(N * nblk)
-                prob = self._f32(N, hc, wc) if trace is not None else None
-                lib.fr_pnet_candidates(_lib.ptr(head), N, hc, wc, float(s), t0, cs, _lib.ptr(lb[li]), _lib.ptr(ls[li]),
-                                       _lib.ptr(lr[li]), _lib.ptr(lc[li]), _lib.ptr(bc), _lib.ptr(prob), self._s)
-                if trace is not None:
-                    trace.setdefault("pnet_head", []).append(head)
-                    trace.setdefault("pnet_prob", []).append(prob)
+                with torch.cuda.stream(main if li == 0 or trace is not None else side):
+                    self._s = _lib.stream_ptr()
+                    head, hc, wc = self.pnet_level(frames, s, trace)
+                    nblk = -(-hc * wc // 256)
+                    bc = self._i32(N * nblk)
+                    prob = self._f32(N, hc, wc) if trace is not None else None
+                    lib.fr_pnet_candidates(_lib.ptr(head), N, hc, wc, float(s), t0, cs, _lib.ptr(lb[li]), _lib.ptr(ls[li]),
+                                           _lib.ptr(lr[li]), _lib.ptr(lc[li]), _lib.ptr(bc), _lib.ptr(prob), self._s)
+                    if trace is not None:
+                        trace.setdefault("pnet_head", []).append(head)
+                        trace.setdefault("pnet_prob", []).append(prob)
+            main.wait_stream(side)
+            self._s = _lib.stream_ptr()
             # per-level NMS 0.5 -> keep_scale survivors; then cross-level NMS 0.7 -> cap_p
             kb, ks, ka, kc = self._nms(lb, ls, lr, 4, lc, nlev * N, 1, cs, 0, 0.5, 0, self.keep_scale)
             b1, s1, a1, c1 = self._nms(kb, ks, ka, 4, kc, N, nlev, self.keep_scale, 1, 0.7, 0, self.cap_p)
