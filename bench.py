@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,11 +91,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import warnings
     from facerecognition_infrenceengine_amd import FaceAnalysis, GalleryMatcher

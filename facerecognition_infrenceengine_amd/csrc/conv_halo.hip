@@ -64,6 +64,8 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
     constexpr int PT = (NPT + WP - 1) / WP;
     constexpr int NWI = BN / 64;                      // weight LDS-DMA instructions per thread per step
     constexpr int NXI = XROWS / 64;                   // halo LDS-DMA instructions per thread per chunk
+    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0;
+    STAMP(tA);
     extern __shared__ __attribute__((aligned(16))) half_t lds[];
     half_t* xs = lds;                                 // [NXBUF][XROWS][HK]
     half_t* ws = lds + NXBUF * XROWS * HK;            // [2][BN][HK]
@@ -186,17 +188,23 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, s01 = 0, s12 = 0, s23 = 0, s34 = 0, s45 = 0;
     if constexpr (LEAN) {
         static_assert(!LEAN || NXBUF == 1, "lean variant keeps one halo buffer");
+        STAMP(tB);
         issue_x(0);
         issue_w(0);
         int tap = 0, c = 0, toff = 0, kw = 0, kh = 0;
         for (int q = 0; q < nq; ++q) {
+            STAMP(t0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // W(q) (and a halo issued at the last chunk end)
+            STAMP(t1);
             __builtin_amdgcn_s_barrier();
+            STAMP(t2);
             if (q + 1 < nq) issue_w(q + 1);
+            STAMP(t3);
             read_frags(a0, b0, q, c, toff, kh, 0);
             mfma_all(a0, b0);
             read_frags(a1, b1, q, c, toff, kh, 1);
             mfma_all(a1, b1);
+            STAMP(t4);
             ++tap; ++kw; ++toff;
             if (kw == 3) { kw = 0; toff += HW - 3; ++kh; }
             if (tap == 9) {
@@ -207,6 +215,8 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
                     issue_x(c);
                 }
             }
+            STAMP(t5);
+            if (STAMPS) { s01 += t1 - t0; s12 += t2 - t1; s23 += t3 - t2; s34 += t4 - t3; s45 += t5 - t4; }
         }
     } else {
     issue_x(0);
@@ -280,10 +290,7 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
     for (; q + 2 < nq; ++q) step(q, std::true_type{});
     for (; q < nq; ++q) step(q, std::false_type{});
     }
-    if (STAMPS && p.stamps && lane == 0) {
-        unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
-        o[0] = s01; o[1] = s12; o[2] = s23; o[3] = s34; o[4] = s45;
-    }
+    STAMP(tC);
 
     // ---- epilogue through LDS: the tile's output is 196 consecutive pixels x BN couts, so it is staged
     // as [px][BN] f16 (row pitch + 16 B against bank conflicts) and moved with 16-byte fully coalesced
@@ -340,6 +347,13 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
         const int4v v = *reinterpret_cast<const int4v*>(ot + px * OP + cc * 8);
         *reinterpret_cast<int4v*>(p.y + (size_t)(m_base + px) * p.Cout + cout0 + cc * 8) = v;
     }
+    if (STAMPS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(tD);
+    if (STAMPS && p.stamps && lane == 0) {
+        unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+        o[0] = s01; o[1] = s12; o[2] = s23; o[3] = s34; o[4] = s45;
+        o[5] = tB - tA; o[6] = tC - tB; o[7] = tD - tC;
+    }
 #endif
 }
 
@@ -349,8 +363,8 @@ static int launch_halo(const HaloP& p, hipStream_t s) {
     constexpr size_t opnd = (size_t)(NXBUF * XROWS * HK + 2 * BN * HK) * sizeof(half_t);
     constexpr size_t epi = (size_t)NPT * 16 * (BN + 8) * sizeof(half_t);          // output staging tile
     constexpr size_t lds = opnd > epi ? opnd : epi;
-    auto kern = (p.stamps && !LEAN) ? conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, true, LEAN>
-                                    : conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, false, LEAN>;
+    auto kern = p.stamps ? conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, true, LEAN>
+                         : conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, false, LEAN>;
     static bool done[2] = {false, false};
     if (!done[p.stamps ? 1 : 0]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

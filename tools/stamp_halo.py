@@ -10,12 +10,14 @@ for shape in ((14, 256, 256), (28, 128, 128)):
     st.zero_()
     bench_conv.run(B, shape[0], shape[0], shape[1], shape[2], iters=3, tag="stamped")
     torch.cuda.synchronize()
-    nb = B if shape[0] == 14 else B * 4
+    nb = (B * 2 if shape[0] == 14 else B * 4)          # lean variant: BN = 128 -> 2 N tiles at Cout = 256
     d = st.reshape(-1, 8)[: nb * 8, :5].double()
     tot = d.sum(1)
-    names = ["h0 mfma+reads", "waits(lgkm,vm)", "barrier", "issue W/X", "h1 mfma+reads"]
+    names = ["wait vmcnt", "barrier", "issue W", "reads+MFMA", "tap bookkeeping / halo reload"]
     print(shape, "per-step cycles (s_memtime ticks, 100MHz?) mean per wave:")
     steps = 9 * shape[1] // 64
     for k, nme in enumerate(names):
         print(f"   {nme:16s} {d[:, k].mean().item() / steps:10.1f}  share {d[:, k].sum().item() / tot.sum().item():.3f}")
     print("   total/step", tot.mean().item() / steps)
+    ph = st.reshape(-1, 8)[: nb * 8, 5:8].double().mean(0)
+    print(f"   phases (cycles/wave): setup {ph[0]:.0f}  K loop {ph[1]:.0f}  epilogue {ph[2]:.0f}")
