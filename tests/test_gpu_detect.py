@@ -142,3 +142,25 @@ def test_align_vs_golden(lib, golden):
     got = out[..., :3].float().cpu().numpy().transpose(0, 3, 1, 2)
     np.testing.assert_allclose(got, want, atol=1e-3)                               # f16 storage
     assert float(out[..., 3:].abs().max()) == 0.0
+
+
+def test_4k_frame_capacity_overflow_vs_oracle(det):
+    """BASELINE config C3 (4K frame, 14 pyramid levels): level 0 has more P-Net candidates than CAP_SCALE, so
+    the deterministic overflow rule (first CAP_SCALE cells in raster order) must match the oracle too."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import synth_frame
+    from facerecognition_infrenceengine_amd import weights
+    from facerecognition_infrenceengine_amd.mtcnn import pyramid_scales
+    fr = synth_frame(2160, 3840, 0)
+    assert len(pyramid_scales(2160, 3840)) == 14
+    p, r, o = weights.synth_mtcnn_states(seed=4321)
+    tr = {}
+    ob, os_, ok = odetect.detect(fr, p, r, o, trace=tr)
+    assert int((tr["pnet_prob"][0] >= 0.6).sum()) > 2048            # the overflow path is really taken
+    boxes, scores, kps, counts = det.detect_batch(torch.from_numpy(fr).cuda()[None].contiguous())
+    n = int(counts[0])
+    assert n == len(os_) and n >= 4
+    np.testing.assert_allclose(scores[0, :n].cpu().numpy(), os_, atol=5e-5)
+    np.testing.assert_allclose(boxes[0, :n].cpu().numpy(), ob, atol=2e-2)
+    np.testing.assert_allclose(kps[0, :n].cpu().numpy(), ok, atol=2e-2)
