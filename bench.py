@@ -138,8 +138,11 @@ def main():
     sync()
     t0 = time.perf_counter()
     faces = 0
+    step_ms = []
     for i in range(args.steps):
-        faces += step(i)[2]
+        ts = time.perf_counter()
+        faces += step(i)[2]                    # ends with the ids on the host (a device sync)
+        step_ms.append((time.perf_counter() - ts) * 1e3)
     sync()
     dt = time.perf_counter() - t0
     tot = torch.tensor([dt, float(faces)], dtype=torch.float64, device=device)
@@ -186,6 +189,8 @@ def main():
                           "gallery_rows": GALLERY_ROWS, "weights": "seeded synthetic",
                           "parallelism": f"frame-shard x{world} + gallery row-shard"},
                "per_face_latency_ms": round(dt / max(faces / world, 1) * 1e3, 4),
+               "p50_step_ms": round(float(np.percentile(step_ms, 50)), 3),
+               "p50_face_latency_ms": round(float(np.percentile(step_ms, 50)) / max(faces / world / args.steps, 1), 4),
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_frames, GALLERY_ROWS)

@@ -124,3 +124,20 @@ def test_r100_batch_independence(r100):
     e_all, _ = r100.forward(xa)
     e_one, _ = r100.forward(xa[3:4].contiguous())
     assert torch.equal(e_all[3:4], e_one)
+
+
+def test_r50_variant_vs_oracle():
+    """buffalo_l's recogniser is an IResNet-50 (SURVEY.md F2): the same kernels run it (arch='r50')."""
+    from facerecognition_infrenceengine_amd import weights
+    from facerecognition_infrenceengine_amd.iresnet import IResNetHIP
+    from oracle import nets as onets
+    st = weights.synth_iresnet_state("r50", seed=77)
+    net = IResNetHIP(st, "r50", "cuda:0")
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand((3, 3, 112, 112), generator=g) * 2 - 1
+    ref = onets.iresnet_forward(st, x, weights.IRESNET_LAYERS["r50"]).numpy()
+    emb, normed = net.forward(nchw_to_nhwc8(x))
+    emb = emb.cpu().numpy()
+    cos = (emb * ref).sum(1) / (np.linalg.norm(emb, axis=1) * np.linalg.norm(ref, axis=1))
+    assert (1 - cos).max() < 1e-3, cos
+    assert abs(net.flops_per_face / 1e9 - 12.6) < 0.2          # 12.62 GFLOP / face (BASELINE.md)
