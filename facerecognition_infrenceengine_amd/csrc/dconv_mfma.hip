@@ -25,7 +25,17 @@ struct DcArgs {
     int Ho, Wo;           // conv output extent (H-KH+1, W-KW+1)
     int regions_x, regions_y;
     const uint8_t* frames; int FH, FW;   // SRC == 1: u8 BGR frames [B,FH,FW,3], resized on the fly
+    unsigned long long* stamps;          // diagnostic (FR_DBG_STAMPS): per-wave phase cycle sums, else NULL
 };
+
+#define DSTAMP(var)                                                                               \
+    do {                                                                                          \
+        if (a.stamps) {                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");            \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+        }                                                                                         \
+    } while (0)
 
 // POOL: 0 none | 1 fused 2x2/s2 ceil max pool in registers (needs RW % 16 == 0) | 2 fused PKxPK/s2 ceil max
 // pool through an LDS conv-output tile (regions step by RSY x RSX conv pixels, RH x RW computed per region).
@@ -199,14 +209,17 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
     }
     if (item0 < nitems) store_tile();
 
+    unsigned long long d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, q01 = 0, q12 = 0, q23 = 0, q34 = 0;
     for (int rr = 0; rr < RPB; ++rr) {
         const int item = item0 + rr;
         if (item >= nitems) break;
+        DSTAMP(d0);
         const int zz = item / per_img, rem = item - zz * per_img;
         const int ry = rem / a.regions_x, rx = rem - ry * a.regions_x;
         const int y0 = ry * RSY, x0 = rx * RSX, img0 = zz * G;
         const bool more = rr + 1 < RPB && item + 1 < nitems;
         if (more) load_tile(item + 1);                   // global loads fly under this item's MFMAs
+        DSTAMP(d1);
 
         float4v acc[C::NT][C::PT];
 #pragma unroll
@@ -255,6 +268,7 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
             }
         }
 
+        DSTAMP(d2);
         // ---- epilogue: bias + PReLU
 #pragma unroll
         for (int i = 0; i < C::NT; ++i) {
@@ -402,10 +416,17 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
                 }
             }
         }
+        DSTAMP(d3);
         if (more) {
             __syncthreads();                             // every wave is done with this item's tiles
             store_tile();
         }
+        DSTAMP(d4);
+        if (a.stamps) { q01 += d1 - d0; q12 += d2 - d1; q23 += d3 - d2; q34 += d4 - d3; }
+    }
+    if (a.stamps && lane == 0) {
+        unsigned long long* o = a.stamps + ((size_t)(blockIdx.x % 4096) * NW + wave) * 4;
+        o[0] = q01; o[1] = q12; o[2] = q23; o[3] = q34;
     }
 }
 
@@ -451,7 +472,9 @@ extern "C" int fr_dconv_mfma_f32(int layer, const float* x, const float* w, cons
                                  const uint8_t* frames, int FH, int FW, fr_stream_t stream) {
     FR_REQUIRE(w && bias && y && B > 0 && H > 0 && W > 0, "fr_dconv_mfma_f32: bad argument");
     FR_REQUIRE((layer == 0) ? (frames && FH > 0 && FW > 0) : (x != nullptr), "fr_dconv_mfma_f32: no input");
-    DcArgs a{x, w, bias, slope, y, head_w, head_b, B, H, W, 0, 0, 0, 0, frames, FH, FW};
+    static long long sp = -1;
+    if (sp < 0) { const char* e = getenv("FR_DBG_STAMPS"); sp = e ? strtoll(e, nullptr, 0) : 0; }
+    DcArgs a{x, w, bias, slope, y, head_w, head_b, B, H, W, 0, 0, 0, 0, frames, FH, FW, (unsigned long long*)sp};
     hipStream_t s = fr_stream(stream);
     int rc = FR_OK;
     switch (layer) {
