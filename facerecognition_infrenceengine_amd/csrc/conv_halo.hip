@@ -34,7 +34,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // scheduling pattern for one half step: 4+PT ds_read_b128 (+ ~3 address VALU each) spread over 4*PT MFMAs
 #define INTERLEAVE_READS_MFMA()                                            \
     do {                                                                   \
-        _Pragma("unroll") for (int g_ = 0; g_ < 4 + PT; ++g_) {            \
+        _Pragma("unroll") for (int g_ = 0; g_ < NA + PT; ++g_) {            \
             __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);             \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             \
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);             \
@@ -56,10 +56,12 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // (4 = two blocks per CU).
 // LEAN: one halo buffer, one fragment set, <= 128 VGPRs -> TWO blocks per CU (16 waves): the fixed cost of a
 // block (first loads, epilogue: ~30 % of a 28x28 tile) and its barrier stalls are covered by the neighbour.
-template <int WN, int NPT, int XROWS, int NXBUF, int MINW, bool STAMPS, bool LEAN = false>
+// NA: 16-cout MFMA tiles per wave (4 = 64 couts; 2 = 32 couts: used by the lean variant so that the 13 pixel
+// tiles split 7/6 over two pixel groups instead of 4/3/3/3 over four - 93 % instead of 81 % balanced).
+template <int WN, int NPT, int XROWS, int NXBUF, int MINW, bool STAMPS, bool LEAN = false, int NA = 4>
 __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int BN = 64 * WN;
+    constexpr int BN = 16 * NA * WN;
     constexpr int WP = 8 / WN;
     constexpr int PT = (NPT + WP - 1) / WP;
     constexpr int NWI = BN / 64;                      // weight LDS-DMA instructions per thread per step
@@ -144,9 +146,9 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
         kbs[j] = kb;
     }
 
-    float4v acc[4][PT];
+    float4v acc[NA][PT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int j = 0; j < PT; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
 
@@ -155,12 +157,12 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
     //   top:  read (a1,b1)(q)            | MFMA half 0 (q)      <- LDS reads fly under the MFMAs
     //   mid:  lgkmcnt(0), counted vmcnt, barrier: W(q+1) landed, W(q)'s buffer free
     //         issue W(q+2) [+ next halo] | read (a0,b0)(q+1)    | MFMA half 1 (q)
-    int4v a0[4], b0[PT], a1[4], b1[PT];       // 8 halves each, kept as 4 dwords (no per-element repacking)
-    auto read_frags = [&](int4v (&a)[4], int4v (&b)[PT], int q, int c, int toff, int kh, int kk) {
-        const half_t* wl = ws + (q & 1) * BN * HK + (wn * 64) * HK;
+    int4v a0[NA], b0[PT], a1[NA], b1[PT];       // 8 halves each, kept as 4 dwords (no per-element repacking)
+    auto read_frags = [&](int4v (&a)[NA], int4v (&b)[PT], int q, int c, int toff, int kh, int kk) {
+        const half_t* wl = ws + (q & 1) * BN * HK + (wn * NA * 16) * HK;
         const char* xl = reinterpret_cast<const char*>(xs + (c & (NXBUF - 1)) * XROWS * HK) + toff * (HK * 2);   // scalar part
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const int row = i * 16 + fr;
             a[i] = *reinterpret_cast<const int4v*>(wl + row * HK + (((kk * 4 + fq) ^ (row & 7)) << 3));
         }
@@ -172,16 +174,16 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
             b[j] = *reinterpret_cast<const int4v*>(xl + hoff[j] + ((cq ^ key) << 4));
         }
     };
-    auto mfma_all = [&](int4v (&a)[4], int4v (&b)[PT]) {
+    auto mfma_all = [&](int4v (&a)[NA], int4v (&b)[PT]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NA; ++i)
 #pragma unroll
             for (int j = 0; j < PT; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a[i]), __builtin_bit_cast(half8, b[j]),
                                                                    acc[i][j], 0, 0, 0);
     };
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a0[i] = a1[i] = int4v{0, 0, 0, 0};
+    for (int i = 0; i < NA; ++i) a0[i] = a1[i] = int4v{0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < PT; ++j) b0[j] = b1[j] = int4v{0, 0, 0, 0};
 
@@ -238,12 +240,12 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
         read_frags(a1, b1, q, c, toff, kh, 1);
         mfma_all(a0, b0);
 #pragma unroll
-        for (int g_ = 0; g_ < 4 + PT; ++g_) {
+        for (int g_ = 0; g_ < NA + PT; ++g_) {
             __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * PT - (4 + PT), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NA * PT - (NA + PT), 0);
         __builtin_amdgcn_sched_barrier(0);
         STAMP(t1);
         int ntap = tap + 1, nkw = kw + 1, ntoff = toff + 1, nkh = kh, nc = c;
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
         read_frags(a0, b0, q + 1, nc, ntoff, nkh, 0);      // harmless on the last step (stays inside the LDS buffers)
         mfma_all(a1, b1);
 #pragma unroll
-        for (int g_ = 0; g_ < 4 + PT; ++g_) {
+        for (int g_ = 0; g_ < NA + PT; ++g_) {
             __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -273,9 +275,9 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * PT - (4 + PT) - 3 * NWI, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NA * PT - (NA + PT) - 3 * NWI, 0);
         } else {
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * PT - (4 + PT), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NA * PT - (NA + PT), 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         // next chunk's halo: issued AFTER W(q+2) so that "all but the youngest NXI" at the next step's wait
@@ -322,8 +324,8 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
             bsel = (rc * 3 + cc) * p.Cout;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int col = wn * 64 + i * 16 + fq * 4;
+        for (int i = 0; i < NA; ++i) {
+            const int col = wn * NA * 16 + i * 16 + fq * 4;
             const int co = cout0 + col;
             float4v v = acc[i][j];
             if (p.bias) v += *reinterpret_cast<const float4v*>(p.bias + bsel + co);
@@ -357,14 +359,14 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
 #endif
 }
 
-template <int WN, int NPT, int XROWS, int NXBUF, int MINW, bool LEAN = false>
+template <int WN, int NPT, int XROWS, int NXBUF, int MINW, bool LEAN = false, int NA = 4>
 static int launch_halo(const HaloP& p, hipStream_t s) {
-    constexpr int BN = 64 * WN;
+    constexpr int BN = 16 * NA * WN;
     constexpr size_t opnd = (size_t)(NXBUF * XROWS * HK + 2 * BN * HK) * sizeof(half_t);
     constexpr size_t epi = (size_t)NPT * 16 * (BN + 8) * sizeof(half_t);          // output staging tile
     constexpr size_t lds = opnd > epi ? opnd : epi;
-    auto kern = p.stamps ? conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, true, LEAN>
-                         : conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, false, LEAN>;
+    auto kern = p.stamps ? conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, true, LEAN, NA>
+                         : conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, false, LEAN, NA>;
     static bool done[2] = {false, false};
     if (!done[p.stamps ? 1 : 0]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -406,8 +408,10 @@ int fr_conv_halo_try(const fr_conv_args* a, hipStream_t s) {
         // FR_HALO_LEAN bit 0: 28x28 layers, bit 1: 14x14 layers run as two lean blocks per CU (default 3 = both)
         static int lean = -1;
         if (lean < 0) { const char* e = getenv("FR_HALO_LEAN"); lean = e ? atoi(e) : 3; }
-        if ((lean & 1) && a->H == 28) rc = launch_halo<2, 13, 320, 1, 4, true>(p, s);
-        else if ((lean & 2) && a->H == 14) rc = launch_halo<2, 13, 256, 1, 4, true>(p, s);
+        static int na2 = -1;        // FR_HALO_NA2=1: 32 couts per wave x 2 pixel groups (7/6 tiles: better balanced, but spills at 128 VGPRs; measured no gain)
+        if (na2 < 0) { const char* e = getenv("FR_HALO_NA2"); na2 = e ? atoi(e) : 0; }
+        if ((lean & 1) && a->H == 28) rc = na2 ? launch_halo<4, 13, 320, 1, 4, true, 2>(p, s) : launch_halo<2, 13, 320, 1, 4, true>(p, s);
+        else if ((lean & 2) && a->H == 14) rc = na2 ? launch_halo<4, 13, 256, 1, 4, true, 2>(p, s) : launch_halo<2, 13, 256, 1, 4, true>(p, s);
         else rc = (a->Cout % 256 == 0) ? launch_halo<4, 13, 320, 2, 2>(p, s) : launch_halo<2, 13, 320, 2, 2>(p, s);
     }
     return rc == FR_OK ? 1 : rc;
