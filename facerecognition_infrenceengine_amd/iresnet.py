@@ -137,9 +137,9 @@ class IResNetHIP:
                 if H in (14, 28) and c.cout % 128 == 0:          # lean variant: BN = 128, two blocks per CU
                     halo = "conv_halo_kernel<2, 13, %d, 1, 4, false, true, 4>" % (256 if H == 14 else 320)
                 elif H == 56 and c.cin == 64 and c.cout == 64:
-                    halo = "conv_halo_kernel<1, 14, 384, 1, 4, false>"
+                    halo = "conv_halo_kernel<1, 14, 384, 1, 4, false, false, 4>"
                 elif H == 112 and c.cin == 64 and c.cout == 64:
-                    halo = "conv_halo_kernel<1, 14, 512, 1, 4, false>"
+                    halo = "conv_halo_kernel<1, 14, 512, 1, 4, false, false, 4>"
             variant = halo or "conv_mfma_kernel<%d, %s, true>" % (2 if c.cout % 128 == 0 else 1,
                                                                   "true" if c.cin == 8 else "false")
             kreal = 27 if c.cin == 8 else c.k * c.k * c.cin       # algorithmic K (stem: 3 real channels)
