@@ -113,12 +113,10 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
     constexpr int NLOAD = SRC == 1 ? C::IH * C::IW : G * C::IH * C::IW * C4;     // float4 slots of one tile
     constexpr int NPF = (NLOAD + C::NTHR - 1) / C::NTHR;
     float4v pf[NPF];
-    // per-slot constants (tile-relative pixel, channel group, LDS offset) decoded ONCE, not per tile
-    int sl_yx[NPF], sl_gc[NPF], sl_lds[NPF];
-#pragma unroll
-    for (int u = 0; u < NPF; ++u) {
-        const int e = tid + u * C::NTHR;
-        int iy = 0, ix = 0, g = 0, c4 = 0, l = -1;
+    // slot e of the tile -> (image g, pixel iy/ix, channel group c4, LDS offset); decoded on the fly: keeping the
+    // decode in registers across tiles cost 3 VGPRs per slot and bought nothing (measured)
+    auto slot = [&](int e, int& iy, int& ix, int& g, int& c4, int& l) {
+        iy = ix = g = c4 = 0; l = -1;
         if (e < NLOAD) {
             if constexpr (SRC == 1) {
                 iy = e / C::IW; ix = e - iy * C::IW;
@@ -132,8 +130,7 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
                 l = g * C::IMG + pix * C::CINS + c4 * 4;
             }
         }
-        sl_yx[u] = (iy << 16) | ix; sl_gc[u] = (g << 16) | c4; sl_lds[u] = l;
-    }
+    };
     auto load_tile = [&](int item) {
         const int zz = item / per_img, rem = item - zz * per_img;
         const int ry = rem / a.regions_x, rx = rem - ry * a.regions_x;
@@ -141,9 +138,11 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
 #pragma unroll
         for (int u = 0; u < NPF; ++u) {
             float4v v = {0.f, 0.f, 0.f, 0.f};
-            const int yy = y0 + (sl_yx[u] >> 16), xx = x0 + (sl_yx[u] & 0xffff);
-            const int n = img0 + (sl_gc[u] >> 16);
-            if (sl_lds[u] >= 0 && n < a.B && yy < a.H && xx < a.W) {
+            int iy, ix, g, c4, l;
+            slot(tid + u * C::NTHR, iy, ix, g, c4, l);
+            const int yy = y0 + iy, xx = x0 + ix;
+            const int n = img0 + g;
+            if (l >= 0 && n < a.B && yy < a.H && xx < a.W) {
                 if constexpr (SRC == 1) {
                     const float ryr = (float)a.FH / (float)a.H, rxr = (float)a.FW / (float)a.W;
                     const DLerp ly = dlerp_coord(yy, ryr, a.FH), lx = dlerp_coord(xx, rxr, a.FW);
@@ -158,7 +157,7 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
                         v[c] = (sv - 127.5f) * 0.0078125f;
                     }
                 } else {
-                    v = *reinterpret_cast<const float4v*>(a.x + (((int64_t)n * a.H + yy) * a.W + xx) * CIN + (sl_gc[u] & 0xffff) * 4);
+                    v = *reinterpret_cast<const float4v*>(a.x + (((int64_t)n * a.H + yy) * a.W + xx) * CIN + c4 * 4);
                 }
             }
             pf[u] = v;
@@ -167,8 +166,10 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
     auto store_tile = [&]() {
 #pragma unroll
         for (int u = 0; u < NPF; ++u) {
-            if (sl_lds[u] >= 0) {
-                float* d = xin + sl_lds[u];
+            int iy, ix, g, c4, l;
+            slot(tid + u * C::NTHR, iy, ix, g, c4, l);
+            if (l >= 0) {
+                float* d = xin + l;
                 d[0] = pf[u][0]; d[1] = pf[u][1]; d[2] = pf[u][2]; d[3] = pf[u][3];
             }
         }
@@ -198,14 +199,21 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
         bias_r[i] = *reinterpret_cast<const float4v*>(a.bias + coW + i * 16);
         slope_r[i] = a.slope ? *reinterpret_cast<const float4v*>(a.slope + coW + i * 16) : float4v{1.f, 1.f, 1.f, 1.f};
     }
-    float hw_r[NHEAD > 0 ? C::NT * 4 * NHEAD : 1];
+    // fused head (P-Net conv3 -> conv4_1|conv4_2) on the matrix pipe: the activation tile sits in the C layout
+    // (lane = pixel j, group kq, register e <-> channel 16*i + 4*kq + e), which IS a B operand with k = kq once one
+    // register e is taken at a time; the A operand is the head weight W[h = lane&15][that channel].  8 MFMAs per
+    // pixel tile replace 48 FMAs + 12 cross-lane reductions, and the weights need NT*4 registers instead of 48.
+    float hw_a[NHEAD > 0 ? C::NT * 4 : 1];
+    float hb_r[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (NHEAD > 0) {
+        static_assert(NHEAD <= 8 && WN == 1, "fused head: all channels of a pixel in one wave");
 #pragma unroll
         for (int i = 0; i < C::NT; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
+                hw_a[i * 4 + e] = li < NHEAD ? a.head_w[(coW + i * 16 + e) * NHEAD + li] : 0.f;
 #pragma unroll
-                for (int k = 0; k < NHEAD; ++k) hw_r[(i * 4 + e) * NHEAD + k] = a.head_w[(coW + i * 16 + e) * NHEAD + k];
+        for (int r = 0; r < 4; ++r) hb_r[r] = (kq * 4 + r) < NHEAD ? a.head_b[kq * 4 + r] : 0.f;
     }
     if (item0 < nitems) store_tile();
 
@@ -363,34 +371,29 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
                 a.y[(((int64_t)n * PH + py) * PW + px) * COUT + cout] = m;
             }
         } else if constexpr (NHEAD > 0) {
+            float4v hd[C::PT];
+#pragma unroll
+            for (int t = 0; t < C::PT; ++t) hd[t] = float4v{hb_r[0], hb_r[1], hb_r[2], hb_r[3]};
+#pragma unroll
+            for (int i = 0; i < C::NT; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int t = 0; t < C::PT; ++t)
+                        hd[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(hw_a[i * 4 + e], acc[i][t][e], hd[t], 0, 0, 0);
+            // D layout: lane (pixel j = li, group kq) holds heads 4*kq .. 4*kq+3
 #pragma unroll
             for (int t = 0; t < C::PT; ++t) {
-                float h[NHEAD > 0 ? NHEAD : 1];
-#pragma unroll
-                for (int k = 0; k < NHEAD; ++k) h[k] = 0.f;
-#pragma unroll
-                for (int i = 0; i < C::NT; ++i)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                        for (int k = 0; k < NHEAD; ++k) h[k] = __builtin_fmaf(acc[i][t][e], hw_r[(i * 4 + e) * NHEAD + k], h[k]);
-                    }
-#pragma unroll
-                for (int k = 0; k < NHEAD; ++k) {
-                    h[k] += __shfl_xor(h[k], 16, 64);
-                    h[k] += __shfl_xor(h[k], 32, 64);
-                    h[k] += a.head_b[k];
-                }
                 const int p = (wm * C::PT + t) * 16 + li;
-                if (kq == 0 && p < C::NPIX) {
-                    const int g = p / (RH * RW), q = p - g * (RH * RW);
-                    const int ty = q / RW, tx = q - ty * RW;
-                    const int n = img0 + g, oy = y0 + ty, ox = x0 + tx;
-                    if (n < a.B && oy < a.Ho && ox < a.Wo) {
-                        float* o = a.y + (((int64_t)n * a.Ho + oy) * a.Wo + ox) * NHEAD;
+                if (p >= C::NPIX || kq * 4 >= NHEAD) continue;
+                const int g = p / (RH * RW), q = p - g * (RH * RW);
+                const int ty = q / RW, tx = q - ty * RW;
+                const int n = img0 + g, oy = y0 + ty, ox = x0 + tx;
+                if (n < a.B && oy < a.Ho && ox < a.Wo) {
+                    float* o = a.y + (((int64_t)n * a.Ho + oy) * a.Wo + ox) * NHEAD + kq * 4;
 #pragma unroll
-                        for (int k = 0; k < NHEAD; ++k) o[k] = h[k];
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        if (kq * 4 + r < NHEAD) o[r] = hd[t][r];
                 }
             }
         } else {
@@ -489,10 +492,13 @@ extern "C" int fr_dconv_mfma_f32(int layer, const float* x, const float* w, cons
                      rc = launch_dc<12, 16, 3, 3, 8, 32, 1, 1, 1, 9, 0, 2, 8, 32, 0, 8, 0>(a, s);
                  break;                                                                                   // P-Net conv2
         case 2:  FR_REQUIRE(H >= 3 && W >= 3 && head_w && head_b, "P3 needs head weights");
-                 if ((int64_t)((H - 2 + 15) / 16) * ((W - 2 + 31) / 32) * B < 4096)
-                     rc = launch_dc<16, 32, 3, 3, 8, 32, 1, 2, 1, 9, 0, 2, 8, 32, 6, 1, 0>(a, s);          // 4 waves, 1 tile
+                 { static int v = -1; if (v < 0) { const char* e = getenv("FR_P3_RPB"); v = e ? atoi(e) : 8; }
+                 if (v == 1 || (int64_t)((H - 2 + 7) / 8) * ((W - 2 + 31) / 32) * B < 8192)
+                     rc = launch_dc<16, 32, 3, 3, 8, 32, 1, 2, 1, 9, 0, 2, 8, 32, 6, 1, 0>(a, s);
+                 else if (v == 2)
+                     rc = launch_dc<16, 32, 3, 3, 8, 32, 1, 2, 1, 9, 0, 2, 8, 32, 6, 2, 0>(a, s);
                  else
-                     rc = launch_dc<16, 32, 3, 3, 16, 32, 1, 2, 1, 9, 0, 2, 16, 32, 6, 4, 0, 8>(a, s);     // 8 waves, 4 tiles
+                     rc = launch_dc<16, 32, 3, 3, 8, 32, 1, 2, 1, 9, 0, 2, 8, 32, 6, 8, 0>(a, s); }
                  break;                                                                                   // P-Net conv3+heads
         case 10: FR_REQUIRE(H == 24 && W == 24, "R1 expects 24x24");                        // conv1 + 3x3/s2 pool -> 11x11
                  rc = launch_dc<4, 28, 3, 3, 22, 22, 1, 2, 1, 9, 2, 3, 22, 22, 0, 4, 0>(a, s); break;

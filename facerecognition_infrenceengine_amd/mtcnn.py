@@ -6,6 +6,7 @@ counts, so a whole batch of frames runs without a host synchronisation.  Convent
 ordering, thresholds, capacities) are those written down in ``oracle/detect.py``.
 """
 import math
+import os
 
 import torch
 
@@ -127,6 +128,7 @@ class MTCNNHIP:
         self.cap_scale, self.keep_scale, self.cap_p, self.cap_r, self.cap_o = cap_scale, keep_scale, cap_p, cap_r, cap_o
         assert cap_scale <= 4096 and cap_p <= 1024 and cap_r <= 1024 and cap_o <= 1024
         self._side = None
+        self._one_stream = os.environ.get("FR_DET_ONE_STREAM") == "1"      # profiling: per-kernel times add up
         d = self.device
         p, r, o = ({k: v.detach().float().cpu() for k, v in s.items()} for s in (pstate, rstate, ostate))
         self.p1 = _MConv(0, p["conv1.weight"], p["conv1.bias"], p["prelu1.weight"], d)
@@ -238,7 +240,7 @@ class MTCNNHIP:
             side = self._side
             side.wait_stream(main)
             for li, s in enumerate(scales):
-                with torch.cuda.stream(main if li == 0 or trace is not None else side):
+                with torch.cuda.stream(main if li == 0 or trace is not None or self._one_stream else side):
                     self._s = _lib.stream_ptr()
                     head, hc, wc = self.pnet_level(frames, s, trace)
                     nblk = -(-hc * wc // 256)
