@@ -44,6 +44,7 @@ SIGNATURES = {
     "fr_conv_nhwc_f16": (_I, [C.POINTER(ConvArgs), _P]),
     "fr_fc_reduce_l2norm": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
     "fr_warp_affine_5pt": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "fr_warp_affine_5pt_slots": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
     "fr_pyramid_resize_norm": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "fr_dconv_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "fr_dconv_mfma_f32": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P]),

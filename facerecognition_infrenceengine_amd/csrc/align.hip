@@ -11,14 +11,16 @@ __constant__ double ARC_DST[5][2] = {{38.2946, 51.6963}, {73.5318, 51.5014}, {56
 __global__ __launch_bounds__(256) void warp_affine_5pt(const uint8_t* __restrict__ frames, int H, int W,
                                                        const float* __restrict__ kps,
                                                        const int32_t* __restrict__ frame_idx,
-                                                       const int32_t* __restrict__ count, int size,
+                                                       const int32_t* __restrict__ count,
+                                                       const int32_t* __restrict__ slot_counts, int slot_cap, int size,
                                                        half_t* __restrict__ out, uint8_t* __restrict__ out_u8,
                                                        float* __restrict__ M_out) {
     const int f = blockIdx.x;
-    const bool valid = count == nullptr || f < *count;
+    // validity: compact list (f < *count), or fixed per-frame slots (slot f = frame*cap + j valid iff j < counts[frame])
+    const bool valid = slot_counts ? ((f % slot_cap) < slot_counts[f / slot_cap]) : (count == nullptr || f < *count);
     __shared__ double inv[6];
     if (threadIdx.x == 0 && valid) {
-        const float* k = kps + (int64_t)f * 10;
+        const float* k = kps + (int64_t)f * 10;      // valid slots only: their kps are finite
         const double sf = (double)size / 112.0;
         double msx = 0, msy = 0, mdx = 0, mdy = 0;
         for (int i = 0; i < 5; ++i) { msx += k[2 * i]; msy += k[2 * i + 1]; mdx += ARC_DST[i][0] * sf; mdy += ARC_DST[i][1] * sf; }
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(256) void warp_affine_5pt(const uint8_t* __restrict
         inv[5] = -(inv[3] * tx + inv[4] * ty);
     }
     __syncthreads();
-    const uint8_t* fr = frames + (int64_t)(valid ? frame_idx[f] : 0) * H * W * 3;
+    const uint8_t* fr = frames + (int64_t)(valid ? (slot_counts ? f / slot_cap : frame_idx[f]) : 0) * H * W * 3;
     half_t* o = out + (int64_t)f * size * size * 8;
     for (int t = threadIdx.x; t < size * size; t += 256) {
         const int y = t / size, x = t - y * size;
@@ -91,8 +93,21 @@ extern "C" int fr_warp_affine_5pt(const uint8_t* frames, int nframes, int H, int
     if (F <= 0) return FR_OK;
     FR_REQUIRE(frames && kps && frame_idx && out_f16_nhwc8, "fr_warp_affine_5pt: null pointer");
     FR_REQUIRE(nframes > 0 && H > 0 && W > 0 && size > 0, "fr_warp_affine_5pt: bad size");
-    warp_affine_5pt<<<F, 256, 0, fr_stream(stream)>>>(frames, H, W, kps, frame_idx, count, size,
+    warp_affine_5pt<<<F, 256, 0, fr_stream(stream)>>>(frames, H, W, kps, frame_idx, count, nullptr, 1, size,
                                                       reinterpret_cast<half_t*>(out_f16_nhwc8), out_u8_bgr, M_out);
+    FR_CHECK_LAUNCH("warp_affine_5pt");
+    return FR_OK;
+}
+
+// Fixed-shape form: faces live in per-frame slots [nframes, cap] with device-side counts (no host sync between
+// detection and embedding); slots beyond a frame's count are zero-filled.
+extern "C" int fr_warp_affine_5pt_slots(const uint8_t* frames, int nframes, int H, int W, const float* kps,
+                                        const int32_t* counts, int cap, int size, void* out_f16_nhwc8,
+                                        fr_stream_t stream) {
+    FR_REQUIRE(frames && kps && counts && out_f16_nhwc8 && nframes > 0 && cap > 0 && H > 0 && W > 0 && size > 0,
+               "fr_warp_affine_5pt_slots: bad argument");
+    warp_affine_5pt<<<nframes * cap, 256, 0, fr_stream(stream)>>>(frames, H, W, kps, nullptr, nullptr, counts, cap, size,
+                                                                  reinterpret_cast<half_t*>(out_f16_nhwc8), nullptr, nullptr);
     FR_CHECK_LAUNCH("warp_affine_5pt");
     return FR_OK;
 }

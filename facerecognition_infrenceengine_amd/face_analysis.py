@@ -115,6 +115,26 @@ class FaceAnalysis:
         out["embedding"], out["normed_embedding"] = emb, normed
         return out
 
+    def detect_embed_slots(self, frames):
+        """Sync-free form for streaming/serving: every frame owns ``cap_o`` face slots.
+
+        frames: uint8 [N,H,W,3] BGR on the device.  Returns device tensors only (no host sync):
+        counts i32 [N]; bbox f32 [N,cap,4]; kps f32 [N,cap,5,2]; det_score f32 [N,cap];
+        embedding / normed_embedding f32 [N*cap,512] (rows of empty slots are meaningless: mask with counts)."""
+        if self.det is None:
+            raise _lib.FrError("FaceAnalysis.prepare() has not been called")
+        N, H, W, _ = frames.shape
+        boxes, scores, kps, counts = self.det.detect_batch(frames)
+        cap = boxes.shape[1]
+        kps = kps.contiguous()
+        with torch.cuda.device(self.device):
+            crops = torch.empty((N * cap, 112, 112, 8), dtype=torch.float16, device=self.device)
+            self.lib.fr_warp_affine_5pt_slots(_lib.ptr(frames), N, H, W, _lib.ptr(kps), _lib.ptr(counts), cap, 112,
+                                              _lib.ptr(crops), _lib.stream_ptr())
+            emb, normed = self.rec.forward(crops)
+        return {"counts": counts, "bbox": boxes, "kps": kps, "det_score": scores, "embedding": emb,
+                "normed_embedding": normed}
+
     # ------------------------------------------------------------------ reference-shaped API
     def get_batch(self, frames):
         """list/array of same-sized BGR uint8 frames -> list (per frame) of lists of Face."""

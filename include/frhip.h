@@ -118,6 +118,12 @@ int fr_warp_affine_5pt(const uint8_t* frames, int nframes, int H, int W, const f
                        const int32_t* frame_idx, const int32_t* count, int F, int size,
                        void* out_f16_nhwc8, uint8_t* out_u8_bgr, float* M_out, fr_stream_t stream);
 
+/* fixed-shape form: kps f32 [nframes*cap,5,2] in per-frame slots, counts i32 [nframes] on the device; slot
+ * (frame, j) is warped iff j < counts[frame], else zero-filled: no host sync between detect and embed. */
+int fr_warp_affine_5pt_slots(const uint8_t* frames, int nframes, int H, int W, const float* kps,
+                             const int32_t* counts, int cap, int size, void* out_f16_nhwc8,
+                             fr_stream_t stream);
+
 /* --------------------------------------------------------------- detect ----
  * a-2  MTCNN cascade (detector half of FaceAnalysis.get, infrenceServer.py:528); the
  * conventions (resize, ordering, capacities) are those of oracle/detect.py. */

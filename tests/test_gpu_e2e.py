@@ -131,3 +131,18 @@ def test_get_is_thread_safe(app):
         assert len(a) == len(b)
         for fa, fb in zip(a, b):
             assert np.array_equal(fa.embedding, fb.embedding)
+
+
+def test_slot_path_equals_compact_path(app):
+    """The sync-free fixed-slot pipeline (bench / streaming) gives the same faces as the compact one."""
+    from make_golden import synth_frame
+    frs = np.ascontiguousarray(np.stack([synth_frame(240, 320, s) for s in (4, 5, 6)]))
+    dev = torch.from_numpy(frs).cuda()
+    a = app.detect_embed_device(dev)
+    b = app.detect_embed_slots(dev)
+    cnt = b["counts"].cpu().tolist()
+    assert cnt == a["counts"]
+    cap = b["bbox"].shape[1]
+    rows = torch.tensor([f * cap + j for f, n in enumerate(cnt) for j in range(n)], device="cuda")
+    assert torch.equal(b["embedding"][rows], a["embedding"])
+    assert torch.equal(b["bbox"].reshape(-1, 4)[rows], a["bbox"])
