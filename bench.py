@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
+    ap.add_argument("--depth", type=int, default=3, help="steps in flight before the oldest one's ids are fetched")
+    ap.add_argument("--one-stream", action="store_true", help="detector and embedder on one stream (no overlap)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
@@ -122,47 +124,71 @@ def main():
     nbatch = min(max(args.steps, 1), 3)
     batches = [synth_frames(FRAMES, H, W, rank * 1000 + i, device) for i in range(nbatch)]
 
+    # two HIP streams: the detector cascade of step i+1 (latency-bound) runs beside the embed convs of step i
+    # (MFMA-bound); align/embed/match of a step wait for its own detector through an event
+    two = not args.one_stream
+    s_det = torch.cuda.Stream(device=device) if two else None
+    s_emb = torch.cuda.Stream(device=device) if two else torch.cuda.current_stream(device)
+
+    # ids leave the device through pinned host buffers + an event: a pageable .cpu() drains both streams
+    q_rows = FRAMES * FACES_PER_FRAME
+    pinned = [{"idx": torch.empty(q_rows, dtype=torch.int64).pin_memory(),
+               "dec": torch.empty(q_rows, dtype=torch.int32).pin_memory(),
+               "counts": torch.empty(FRAMES, dtype=torch.int32).pin_memory()} for _ in range(args.depth)]
+
     def enqueue(i):
-        """One step, enqueued without any host synchronisation: fixed per-frame face slots, device-side counts."""
-        r = app.detect_embed_slots(batches[i % nbatch])
-        idx, score = sharded.match(r["normed_embedding"])
-        dec = gm.decide_device(idx, score, 0.4)
-        return idx, dec, r["counts"]
+        """One step, enqueued without any host synchronisation: fixed per-frame face slots, device-side counts,
+        asynchronous copy of the ids / decisions / counts to pinned host memory."""
+        host = pinned[i % args.depth]
+        with torch.cuda.stream(s_emb):
+            r = app.detect_embed_slots(batches[i % nbatch], det_stream=s_det)
+            idx, score = sharded.match(r["normed_embedding"])
+            dec = gm.decide_device(idx, score, 0.4)
+            host["idx"].copy_(idx.to(torch.int64), non_blocking=True)
+            host["dec"].copy_(dec.to(torch.int32), non_blocking=True)
+            host["counts"].copy_(r["counts"], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(s_emb)
+        return host, ev, (idx, dec, r)
 
     def fetch(pending):
         """ids on the host = end of the step; faces = detected faces (slots beyond a frame's count are ignored)."""
-        idx, dec, counts = pending
-        idx.cpu(); dec.cpu()
-        return int(counts.cpu().sum())
+        host, ev, _keep = pending
+        ev.synchronize()
+        return int(host["counts"].sum())
+
+    from collections import deque
 
     def step(i, pending):
-        """Software pipeline of depth 2: step i is enqueued before step i-1's ids are pulled to the host, so the
-        GPU never waits for the Python driver between steps."""
-        nxt = enqueue(i)
-        done = fetch(pending) if pending is not None else 0
-        return nxt, done
+        """Software pipeline of depth args.depth: step i is enqueued before step i-depth+1's ids are pulled to the
+        host, so neither HIP stream waits for the Python driver between steps."""
+        pending.append(enqueue(i))
+        return fetch(pending.popleft()) if len(pending) >= args.depth else 0
+
+    def drain(pending):
+        n = 0
+        while pending:
+            n += fetch(pending.popleft())
+        return n
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    pending = None
+    pending = deque()
     for i in range(args.warmup):
-        pending, _ = step(i, pending)
-    if pending is not None:
-        fetch(pending)
+        step(i, pending)
+    drain(pending)
     sync()
     t0 = time.perf_counter()
     faces = 0
     step_ms = []
-    pending = None
     for i in range(args.steps):
         ts = time.perf_counter()
-        pending, n = step(i, pending)
-        faces += n
+        faces += step(i, pending)
         step_ms.append((time.perf_counter() - ts) * 1e3)
-    faces += fetch(pending)                    # drain: all K steps' ids are on the host inside the timed region
+    faces += drain(pending)                    # all K steps' ids are on the host inside the timed region
     sync()
     dt = time.perf_counter() - t0
     tot = torch.tensor([dt, float(faces)], dtype=torch.float64, device=device)

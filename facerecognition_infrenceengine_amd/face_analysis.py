@@ -115,18 +115,33 @@ class FaceAnalysis:
         out["embedding"], out["normed_embedding"] = emb, normed
         return out
 
-    def detect_embed_slots(self, frames):
+    def detect_embed_slots(self, frames, det_stream=None):
         """Sync-free form for streaming/serving: every frame owns ``cap_o`` face slots.
 
         frames: uint8 [N,H,W,3] BGR on the device.  Returns device tensors only (no host sync):
         counts i32 [N]; bbox f32 [N,cap,4]; kps f32 [N,cap,5,2]; det_score f32 [N,cap];
-        embedding / normed_embedding f32 [N*cap,512] (rows of empty slots are meaningless: mask with counts)."""
+        embedding / normed_embedding f32 [N*cap,512] (rows of empty slots are meaningless: mask with counts).
+
+        det_stream: optional second HIP stream for the detector.  Align + embed stay on the current stream and
+        wait for the detector through an event, but the detector does NOT wait for work already queued on the
+        current stream, so batch i+1's cascade (latency-bound, leaves CU slots idle) runs beside batch i's embed
+        convs (MFMA-bound).  The caller guarantees ``frames`` is complete before this call is made (it is when the
+        frames were produced on ``det_stream`` or synchronised earlier)."""
         if self.det is None:
             raise _lib.FrError("FaceAnalysis.prepare() has not been called")
         N, H, W, _ = frames.shape
-        boxes, scores, kps, counts = self.det.detect_batch(frames)
+        cur = torch.cuda.current_stream(self.device)
+        if det_stream is None:
+            boxes, scores, kps, counts = self.det.detect_batch(frames)
+            kps = kps.contiguous()
+        else:
+            with torch.cuda.stream(det_stream):
+                boxes, scores, kps, counts = self.det.detect_batch(frames)
+                kps = kps.contiguous()
+            cur.wait_stream(det_stream)
+            for t in (boxes, scores, kps, counts):
+                t.record_stream(cur)
         cap = boxes.shape[1]
-        kps = kps.contiguous()
         with torch.cuda.device(self.device):
             crops = torch.empty((N * cap, 112, 112, 8), dtype=torch.float16, device=self.device)
             self.lib.fr_warp_affine_5pt_slots(_lib.ptr(frames), N, H, W, _lib.ptr(kps), _lib.ptr(counts), cap, 112,

@@ -146,3 +146,26 @@ def test_slot_path_equals_compact_path(app):
     rows = torch.tensor([f * cap + j for f, n in enumerate(cnt) for j in range(n)], device="cuda")
     assert torch.equal(b["embedding"][rows], a["embedding"])
     assert torch.equal(b["bbox"].reshape(-1, 4)[rows], a["bbox"])
+
+
+def test_two_stream_overlap_equals_single_stream(app):
+    """Detector on its own HIP stream (overlapping the previous batch's embed): same results, batch after batch."""
+    from make_golden import synth_frame
+    batches = [torch.from_numpy(np.ascontiguousarray(np.stack([synth_frame(240, 320, s + k) for s in (10, 20)]))).cuda()
+               for k in range(3)]
+    want = [app.detect_embed_slots(b) for b in batches]
+    torch.cuda.synchronize()
+    s_det, s_emb = torch.cuda.Stream(), torch.cuda.Stream()
+    got = []
+    with torch.cuda.stream(s_emb):
+        for _ in range(2):                      # second round reuses freed blocks across the streams
+            got = [app.detect_embed_slots(b, det_stream=s_det) for b in batches]
+    torch.cuda.synchronize()
+    for w, g in zip(want, got):
+        assert torch.equal(w["counts"], g["counts"])
+        cap = w["bbox"].shape[1]
+        valid = (torch.arange(cap, device="cuda")[None, :] < w["counts"][:, None]).reshape(-1)   # empty slots: undefined
+        assert valid.any()
+        for k in ("bbox", "kps", "det_score", "embedding", "normed_embedding"):
+            a, b = w[k].reshape(valid.numel(), -1)[valid], g[k].reshape(valid.numel(), -1)[valid]
+            assert torch.equal(a, b), k
