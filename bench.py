@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
     ap.add_argument("--depth", type=int, default=3, help="steps in flight before the oldest one's ids are fetched")
+    ap.add_argument("--prio", default="none", choices=["none", "det", "emb"], help="stream given high priority")
     ap.add_argument("--one-stream", action="store_true", help="detector and embedder on one stream (no overlap)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -127,8 +128,9 @@ def main():
     # two HIP streams: the detector cascade of step i+1 (latency-bound) runs beside the embed convs of step i
     # (MFMA-bound); align/embed/match of a step wait for its own detector through an event
     two = not args.one_stream
-    s_det = torch.cuda.Stream(device=device) if two else None
-    s_emb = torch.cuda.Stream(device=device) if two else torch.cuda.current_stream(device)
+    s_det = torch.cuda.Stream(device=device, priority=-1 if args.prio == "det" else 0) if two else None
+    s_emb = (torch.cuda.Stream(device=device, priority=-1 if args.prio == "emb" else 0) if two
+             else torch.cuda.current_stream(device))
 
     # ids leave the device through pinned host buffers + an event: a pageable .cpu() drains both streams
     q_rows = FRAMES * FACES_PER_FRAME

@@ -34,6 +34,8 @@ SIGNATURES = {
     "fr_l2norm_rows_f32": (_I, [_P, _P, _I, _I, _P]),
     "fr_gallery_match_workspace": (_Z, [_I, _L]),
     "fr_gallery_match_f32": (_I, [_P, _P, _I, _L, _I, _L, _P, _P, _P, _Z, _P]),
+    "fr_gallery_match_view_f32": (_I, [_P, _P, _P, _I, _L, _I, _P, _P, _P, _Z, _P]),
+    "fr_gallery_update_rows_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "fr_gallery_match_f16_workspace": (_Z, [_I, _L]),
     "fr_gallery_match_f16": (_I, [_P, _P, _P, _I, _L, _I, _L, _P, _P, _P, _Z, _P]),
     "fr_f32_to_f16": (_I, [_P, _P, _L, _P]),

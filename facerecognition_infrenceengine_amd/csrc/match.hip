@@ -22,7 +22,11 @@ __device__ __forceinline__ void take_better(float& bs, int64_t& bi, float s, int
     if (s > bs || (s == bs && i < bi && i >= 0)) { bs = s; bi = i; }
 }
 
+// VIEW: row r of the scanned gallery is storage slot view[r] of G (a per-company view of one device-resident
+// slab, no copy of the rows); the winner index is the VIEW position, so the order/tie rule is the view's.
+template <bool VIEW>
 __global__ __launch_bounds__(256) void gallery_scan_f32(const float* __restrict__ Q, const float* __restrict__ G,
+                                                        const int64_t* __restrict__ view,
                                                         int F, int64_t N, float* __restrict__ ws_score,
                                                         int64_t* __restrict__ ws_idx) {
     __shared__ __attribute__((aligned(16))) float qs[QG * QPAD];
@@ -43,7 +47,8 @@ __global__ __launch_bounds__(256) void gallery_scan_f32(const float* __restrict_
     for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
         const int64_t row = t * 32 + r;
         const bool ok = row < N;
-        const float* gp = G + (ok ? row : 0) * GD + 4 * h;
+        const int64_t slot = VIEW ? (ok ? view[row] : 0) : (ok ? row : 0);
+        const float* gp = G + slot * GD + 4 * h;
         const float* qp = &qs[r * QPAD + 4 * h];
         float16v acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
@@ -113,26 +118,76 @@ extern "C" size_t fr_gallery_match_workspace(int F, int64_t N) {
     return per * (sizeof(float) + sizeof(int64_t)) + 512;
 }
 
-extern "C" int fr_gallery_match_f32(const float* Q, const float* G, int F, int64_t N, int D, int64_t row_offset,
-                                    int64_t* out_idx, float* out_score, void* workspace, size_t workspace_bytes,
-                                    fr_stream_t stream) {
-    FR_REQUIRE(D == GD, "fr_gallery_match_f32: D must be %d (got %d)", GD, D);
-    FR_REQUIRE(F >= 0 && N >= 0, "fr_gallery_match_f32: negative size");
+static int gallery_match_launch(const char* who, const float* Q, const float* G, const int64_t* view, int F, int64_t N,
+                                int D, int64_t row_offset, int64_t* out_idx, float* out_score, void* workspace,
+                                size_t workspace_bytes, fr_stream_t stream) {
+    FR_REQUIRE(D == GD, "%s: D must be %d (got %d)", who, GD, D);
+    FR_REQUIRE(F >= 0 && N >= 0, "%s: negative size", who);
     if (F == 0) return FR_OK;
-    FR_REQUIRE(Q && out_idx && out_score && (G || N == 0), "fr_gallery_match_f32: null pointer");
+    FR_REQUIRE(Q && out_idx && out_score && (G || N == 0), "%s: null pointer", who);
     FR_REQUIRE(workspace && workspace_bytes >= fr_gallery_match_workspace(F, N),
-               "fr_gallery_match_f32: workspace too small (%zu < %zu)", workspace_bytes,
-               fr_gallery_match_workspace(F, N));
+               "%s: workspace too small (%zu < %zu)", who, workspace_bytes, fr_gallery_match_workspace(F, N));
     const int nblk = scan_blocks(N);
     float* ws_score = reinterpret_cast<float*>(workspace);
     size_t off = ((size_t)nblk * F * sizeof(float) + 255) & ~(size_t)255;
     int64_t* ws_idx = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(workspace) + off);
     hipStream_t s = fr_stream(stream);
     dim3 grid(nblk, (F + QG - 1) / QG);
-    gallery_scan_f32<<<grid, 256, 0, s>>>(Q, G, F, N, ws_score, ws_idx);
+    if (view) gallery_scan_f32<true><<<grid, 256, 0, s>>>(Q, G, view, F, N, ws_score, ws_idx);
+    else gallery_scan_f32<false><<<grid, 256, 0, s>>>(Q, G, nullptr, F, N, ws_score, ws_idx);
     FR_CHECK_LAUNCH("gallery_scan_f32");
     gallery_reduce<<<fr_cdiv(F, 64), 64, 0, s>>>(ws_score, ws_idx, nblk, F, row_offset, out_idx, out_score);
     FR_CHECK_LAUNCH("gallery_reduce");
+    return FR_OK;
+}
+
+extern "C" int fr_gallery_match_f32(const float* Q, const float* G, int F, int64_t N, int D, int64_t row_offset,
+                                    int64_t* out_idx, float* out_score, void* workspace, size_t workspace_bytes,
+                                    fr_stream_t stream) {
+    return gallery_match_launch("fr_gallery_match_f32", Q, G, nullptr, F, N, D, row_offset, out_idx, out_score,
+                                workspace, workspace_bytes, stream);
+}
+
+extern "C" int fr_gallery_match_view_f32(const float* Q, const float* G, const int64_t* view, int F, int64_t Nview,
+                                         int D, int64_t* out_idx, float* out_score, void* workspace,
+                                         size_t workspace_bytes, fr_stream_t stream) {
+    FR_REQUIRE(view || Nview == 0, "fr_gallery_match_view_f32: null view");
+    // Nview == 0: the scan kernel sees no tiles and the reduce writes (-1, -1)
+    return gallery_match_launch("fr_gallery_match_view_f32", Q, G, Nview ? view : nullptr, F, Nview, D, 0, out_idx,
+                                out_score, workspace, workspace_bytes, stream);
+}
+
+// ---------------------------------------------------------------- in-place gallery row update
+// one wave per row: G[slots[i]] = rows[i] (optionally / ||rows[i]||, the ingest's normalise)
+__global__ void gallery_update_rows(float* __restrict__ G, const int64_t* __restrict__ slots,
+                                    const float* __restrict__ rows, int n, int normalise) {
+    const int i = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const float* p = rows + (int64_t)i * GD;
+    float4 v0 = *reinterpret_cast<const float4*>(p + lane * 4);
+    float4 v1 = *reinterpret_cast<const float4*>(p + 256 + lane * 4);
+    if (normalise) {
+        float ss = v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w;
+        ss += v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
+        ss = wave_sum(ss);
+        const float nrm = sqrtf(ss);
+        v0.x /= nrm; v0.y /= nrm; v0.z /= nrm; v0.w /= nrm;
+        v1.x /= nrm; v1.y /= nrm; v1.z /= nrm; v1.w /= nrm;
+    }
+    float* o = G + slots[i] * GD;
+    *reinterpret_cast<float4*>(o + lane * 4) = v0;
+    *reinterpret_cast<float4*>(o + 256 + lane * 4) = v1;
+}
+
+extern "C" int fr_gallery_update_rows_f32(float* G, const int64_t* slots, const float* rows, int n, int D,
+                                          int normalise, fr_stream_t stream) {
+    FR_REQUIRE(D == GD, "fr_gallery_update_rows_f32: D must be %d (got %d)", GD, D);
+    FR_REQUIRE(n >= 0, "fr_gallery_update_rows_f32: negative size");
+    if (n == 0) return FR_OK;
+    FR_REQUIRE(G && slots && rows, "fr_gallery_update_rows_f32: null pointer");
+    gallery_update_rows<<<fr_cdiv(n, 4), 256, 0, fr_stream(stream)>>>(G, slots, rows, n, normalise);
+    FR_CHECK_LAUNCH("gallery_update_rows");
     return FR_OK;
 }
 

@@ -104,3 +104,133 @@ class GalleryMatcher:
         idx_h, score_h, dec_h = idx.cpu().numpy(), score.cpu().numpy(), dec.cpu().numpy()
         ids = [self.ids[i] if (d == 1 and i >= 0) else None for i, d in zip(idx_h, dec_h)]
         return ids, score_h, idx_h
+
+
+class DeviceGallery:
+    """One device-resident slab of gallery row slots with in-place updates + per-company views
+    (SURVEY.md section 8f row 2).
+
+    The reference keeps ``dict[id -> float32[512]]`` (infrenceServer.py:46), inserts/overwrites entries on
+    every incremental sync (:271-273, :324-326), deletes inactive people (:250-252) and, PER FRAME, filters
+    the dict by the company's member ids (:343-380).  Here the rows live once in HBM: ``upsert`` writes
+    changed rows into their slots in place (new ids take a free slot, capacity doubles when full),
+    ``remove`` frees slots, and a company view is only an int64 slot list in the reference's dict order -
+    ``GalleryView.match_device`` scans the slab through it (no per-company copy of the rows).
+    """
+
+    def __init__(self, device="cuda:0", capacity=1024):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.G = torch.zeros((max(int(capacity), 1), DIM), dtype=torch.float32, device=self.device)
+        self.slot_of = {}                # id -> slot
+        self._free = []                  # freed slots, reused LIFO
+        self._next = 0                   # first never-used slot
+        self.generation = 0              # bumps on every membership change (views check it)
+
+    def __len__(self):
+        return len(self.slot_of)
+
+    @property
+    def capacity(self):
+        return self.G.shape[0]
+
+    def _grow(self, need):
+        cap = self.capacity
+        while cap < need:
+            cap *= 2
+        if cap != self.capacity:
+            G = torch.zeros((cap, DIM), dtype=torch.float32, device=self.device)
+            G[: self.capacity].copy_(self.G)
+            self.G = G
+
+    def upsert(self, ids, rows, normalise=False):
+        """rows: float32 [n,512] (host or device).  Existing ids are overwritten in place (same slot), new
+        ids take a slot.  ``normalise`` applies v/||v|| on the device (the manager normalises on the host with
+        NumPy, bit-exactly as infrenceServer.py:271, and passes False)."""
+        ids = list(ids)
+        rows = torch.as_tensor(np.asarray(rows, np.float32) if not torch.is_tensor(rows) else rows)
+        rows = rows.to(self.device, torch.float32).contiguous().reshape(-1, DIM)
+        if len(ids) != rows.shape[0]:
+            raise ValueError("ids and rows disagree")
+        if not ids:
+            return
+        last = {i: k for k, i in enumerate(ids)}          # an id given twice: the last row wins, as dict assignment
+        if len(last) != len(ids):
+            keep = sorted(last.values())
+            ids = [ids[k] for k in keep]
+            rows = rows[torch.tensor(keep, device=self.device)]
+        new = [i for i in ids if i not in self.slot_of]
+        self._grow(self._next + max(len(new) - len(self._free), 0))
+        for i in new:
+            if self._free:
+                self.slot_of[i] = self._free.pop()
+            else:
+                self.slot_of[i] = self._next
+                self._next += 1
+        if new:
+            self.generation += 1
+        slots = torch.tensor([self.slot_of[i] for i in ids], dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            self.lib.fr_gallery_update_rows_f32(_lib.ptr(self.G), _lib.ptr(slots), _lib.ptr(rows), len(ids), DIM,
+                                                1 if normalise else 0, _lib.stream_ptr())
+
+    def remove(self, ids):
+        n = 0
+        for i in ids:
+            s = self.slot_of.pop(i, None)
+            if s is not None:
+                self._free.append(s)
+                n += 1
+        if n:
+            self.generation += 1
+        return n
+
+    def view(self, ids):
+        """View over the given ids, in the given order (ids not in the gallery are skipped)."""
+        return GalleryView(self, [i for i in ids if i in self.slot_of])
+
+
+class GalleryView:
+    """Ordered subset of a ``DeviceGallery``: the rows one company's frames are matched against."""
+
+    def __init__(self, gallery, ids):
+        self.gallery, self.ids = gallery, list(ids)
+        self.generation = gallery.generation
+        self.lib, self.device = gallery.lib, gallery.device
+        self.slots = torch.tensor([gallery.slot_of[i] for i in self.ids], dtype=torch.int64, device=self.device)
+        self._ws = None
+
+    def __len__(self):
+        return len(self.ids)
+
+    def rows(self):
+        """The view's rows as a [N,512] device tensor (a copy; for tests / export)."""
+        return self.gallery.G[self.slots]
+
+    def match_device(self, Q, renormalise=True):
+        """As ``GalleryMatcher.match_device``; idx is the position in ``self.ids`` (-1: empty view)."""
+        if self.generation != self.gallery.generation:
+            raise _lib.FrError("GalleryView is stale: the gallery's membership changed after the view was made")
+        Q = Q.to(self.device, torch.float32).contiguous().reshape(-1, DIM)
+        F = Q.shape[0]
+        idx = torch.empty(F, dtype=torch.int64, device=self.device)
+        score = torch.empty(F, dtype=torch.float32, device=self.device)
+        if F == 0:
+            return idx, score
+        with torch.cuda.device(self.device):
+            s = _lib.stream_ptr()
+            if renormalise:
+                Qn = torch.empty_like(Q)
+                self.lib.fr_l2norm_rows_f32(_lib.ptr(Q), _lib.ptr(Qn), F, DIM, s)
+                Q = Qn
+            need = self.lib.fr_gallery_match_workspace(F, len(self.ids))
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self.lib.fr_gallery_match_view_f32(_lib.ptr(Q), _lib.ptr(self.gallery.G), _lib.ptr(self.slots), F,
+                                               len(self.ids), DIM, _lib.ptr(idx), _lib.ptr(score),
+                                               _lib.ptr(self._ws), self._ws.numel(), s)
+        return idx, score
+
+    decide_device = GalleryMatcher.decide_device
+    match = GalleryMatcher.match

@@ -93,7 +93,9 @@ class EmbeddingManager:
         self.is_initial_load = True
         self.sync_interval = sync_interval
         self.sync_thread, self.running = None, False
-        self._matchers = {}                  # company id -> (GalleryMatcher, metadata)
+        self._gallery = None                 # DeviceGallery: one slab of rows in HBM, updated in place
+        self._dirty, self._gone = {}, set()  # ids changed / removed since the slab was last brought up to date
+        self._matchers = {}                  # company id -> (GalleryView, metadata), rebuilt after a sync
         self._initial_load()
 
     # ---- ingest (infrenceServer.py:260-341): unpickle, divide by the norm
@@ -105,6 +107,8 @@ class EmbeddingManager:
                 read = self.store.read_employee_embedding if kind == "employee" else self.store.read_visitor_embedding
                 embedding = pickle.loads(read(entry["embeddingId"]))
                 self.embeddings[_id] = embedding / np.linalg.norm(embedding)
+                self._dirty[_id] = None
+                self._gone.discard(_id)
                 if kind == "employee":
                     self.employee_metadata[_id] = {
                         "name": d.get("employeeName", "Unknown"), "employeeId": d.get("employeeId", "Unknown"),
@@ -133,6 +137,8 @@ class EmbeddingManager:
                 if _id in self.embeddings:
                     del self.embeddings[_id]
                     self.employee_metadata.pop(_id, None)
+                    self._dirty.pop(_id, None)
+                    self._gone.add(_id)
             self._matchers.clear()
 
     def _sync_embeddings(self):
@@ -183,17 +189,30 @@ class EmbeddingManager:
         with self.embeddings_lock:
             return dict(self.embeddings), dict(self.employee_metadata)
 
+    def _flush_to_device(self):
+        """Bring the device slab up to date: only rows that changed since the last flush travel (in-place row
+        writes); removed people free their slots.  Called under the lock."""
+        from .gallery import DeviceGallery
+        if self._gallery is None:
+            self._gallery = DeviceGallery(self.device, capacity=max(1024, 2 * len(self.embeddings)))
+        if self._gone:
+            self._gallery.remove(self._gone)
+            self._gone = set()
+        if self._dirty:
+            ids = list(self._dirty)
+            self._gallery.upsert(ids, np.stack([self.embeddings[i] for i in ids]), normalise=False)  # unit at ingest
+            self._dirty = {}
+
     def get_matcher_for_company(self, company_id):
-        """Device-resident matcher for the company's rows, built once per sync (not per frame)."""
-        from .gallery import GalleryMatcher
+        """(view, metadata): the company's rows as an ordered view of the device-resident slab.  The membership
+        queries the reference issues per frame (infrenceServer.py:351-367) run once per sync; rows are never
+        copied per company, and a sync rewrites only the rows whose documents changed."""
         with self.embeddings_lock:
+            self._flush_to_device()
             hit = self._matchers.get(company_id)
-            if hit is None:
+            if hit is None or hit[0].generation != self._gallery.generation:
                 ids = self._company_rows(company_id) if company_id is not None else list(self.embeddings)
-                m = GalleryMatcher(self.device)
-                rows = np.stack([self.embeddings[i] for i in ids]) if ids else np.zeros((0, 512), np.float32)
-                m.set_rows(ids, rows, normalise=False)       # rows were normalised at ingest
-                hit = (m, {i: self.employee_metadata[i] for i in ids})
+                hit = (self._gallery.view(ids), {i: self.employee_metadata[i] for i in ids})
                 self._matchers[company_id] = hit
             return hit
 

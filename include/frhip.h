@@ -48,6 +48,17 @@ size_t fr_gallery_match_workspace(int F, int64_t N);
 int fr_gallery_match_f32(const float* Q, const float* G, int F, int64_t N, int D,
                          int64_t row_offset, int64_t* out_idx, float* out_score,
                          void* workspace, size_t workspace_bytes, fr_stream_t stream);
+/* Gallery slab + views (replaces the per-frame dict filtering of
+ * infrenceServer.py:343-380 and the dict inserts/deletes of :260-341, :234-258).  G is one device-resident
+ * slab of row slots [capacity,512]; a view is the int64 slot list of one company in the reference's dict
+ * order.  fr_gallery_match_view_f32 scans rows G[view[0..Nview)] without copying them; out_idx is the VIEW
+ * position (so "first maximum in iteration order" is the view's order), -1 when Nview == 0.
+ * fr_gallery_update_rows_f32 writes rows[i] (optionally v/||v||, :271,324) into slot slots[i] in place. */
+int fr_gallery_match_view_f32(const float* Q, const float* G, const int64_t* view, int F, int64_t Nview, int D,
+                              int64_t* out_idx, float* out_score, void* workspace, size_t workspace_bytes,
+                              fr_stream_t stream);
+int fr_gallery_update_rows_f32(float* G, const int64_t* slots, const float* rows, int n, int D, int normalise,
+                               fr_stream_t stream);
 /* f16 gallery (1 M .. 10 M rows): coarse scan on the f16 matrix cores keeps the top FR_TOPK rows per
  * query, which are then re-scored exactly in f32 against G32 (may be NULL: scores then come from the
  * f16 scan) and picked by max score / lowest row.  G16: f16 [N,512] (fr_f32_to_f16 of the unit rows). */

@@ -169,3 +169,35 @@ def test_two_stream_overlap_equals_single_stream(app):
         for k in ("bbox", "kps", "det_score", "embedding", "normed_embedding"):
             a, b = w[k].reshape(valid.numel(), -1)[valid], g[k].reshape(valid.numel(), -1)[valid]
             assert torch.equal(a, b), k
+
+
+def test_detector_is_bit_stable_beside_the_embedder(app):
+    """Regression for a cross-stream hazard measured on MI355X: with packed-f32 VALU ops in the detector's kernels,
+    lanes 48-63 of their results went stale whenever the embedder's conv kernels shared the SIMDs (DESIGN.md 4.7);
+    the library is built without those ops.  Detector outputs must be bit-identical to a solo run while the embed
+    convs run on a second stream."""
+    from make_golden import synth_frame
+    batches = [torch.from_numpy(np.ascontiguousarray(np.stack([synth_frame(240, 320, s + k) for s in (10, 20)]))).cuda()
+               for k in range(3)]
+    crops = (torch.rand((64, 112, 112, 8), device="cuda") * 2 - 1).half()
+    crops[..., 3:] = 0
+    want = [app.det.detect_batch(b) for b in batches]
+    emb0 = app.rec.forward(crops)[0].clone()
+    torch.cuda.synchronize()
+    s_det, s_emb = torch.cuda.Stream(), torch.cuda.Stream()
+    for rep in range(8):
+        got, embs = [], []
+        for b in batches:
+            with torch.cuda.stream(s_emb):
+                embs.append(app.rec.forward(crops)[0])
+            with torch.cuda.stream(s_det):
+                got.append(app.det.detect_batch(b))
+        torch.cuda.synchronize()
+        for e in embs:
+            assert torch.equal(e, emb0)
+        for w, g in zip(want, got):
+            assert torch.equal(w[3], g[3])
+            cap = w[0].shape[1]
+            valid = (torch.arange(cap, device="cuda")[None, :] < w[3][:, None]).reshape(-1)
+            for a, b in zip(w[:3], g[:3]):
+                assert torch.equal(a.reshape(valid.numel(), -1)[valid], b.reshape(valid.numel(), -1)[valid]), rep
