@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
     ap.add_argument("--depth", type=int, default=3, help="steps in flight before the oldest one's ids are fetched")
+    ap.add_argument("--ingest", default="resident", choices=["resident", "pinned"],
+                    help="resident: frames already in HBM (the headline metric); pinned: every step's frames cross "
+                         "PCIe from a pinned host ring on a copy stream (reported in DESIGN.md, never the headline)")
     ap.add_argument("--prio", default="none", choices=["none", "det", "emb"], help="stream given high priority")
     ap.add_argument("--one-stream", action="store_true", help="detector and embedder on one stream (no overlap)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
@@ -125,6 +128,13 @@ def main():
     nbatch = min(max(args.steps, 1), 3)
     batches = [synth_frames(FRAMES, H, W, rank * 1000 + i, device) for i in range(nbatch)]
 
+    ingest = None
+    if args.ingest == "pinned":
+        from facerecognition_infrenceengine_amd.ingest import FrameIngest
+        ingest = FrameIngest(FRAMES, H, W, device, depth=args.depth + 1)
+        for k in range(ingest.depth):       # what the capture side would have written
+            ingest.host_buffer(k)[...] = batches[k % nbatch].cpu().numpy()
+
     # two HIP streams: the detector cascade of step i+1 (latency-bound) runs beside the embed convs of step i
     # (MFMA-bound); align/embed/match of a step wait for its own detector through an event
     two = not args.one_stream
@@ -143,7 +153,12 @@ def main():
         asynchronous copy of the ids / decisions / counts to pinned host memory."""
         host = pinned[i % args.depth]
         with torch.cuda.stream(s_emb):
-            r = app.detect_embed_slots(batches[i % nbatch], det_stream=s_det)
+            if ingest is not None:          # PCIe-inclusive variant: pinned host ring -> device on a copy stream
+                frames, ready = ingest.upload(i)
+                r = app.detect_embed_slots(frames, det_stream=s_det, ready_event=ready)
+                ingest.release(i)           # the warp (last reader of the frames) is queued on this stream by now
+            else:
+                r = app.detect_embed_slots(batches[i % nbatch], det_stream=s_det)
             idx, score = sharded.match(r["normed_embedding"])
             dec = gm.decide_device(idx, score, 0.4)
             host["idx"].copy_(idx.to(torch.int64), non_blocking=True)
@@ -233,7 +248,7 @@ def main():
                "vs_baseline": None, "dtype": "f16", "data": "synthetic",
                "config": {"workload": "C2: 64x1080p synthetic frames/GPU, MTCNN full pyramid (caps 512/64/4), "
                                       "ArcFace r100 f16 embed, 10k-row cosine gallery (row-sharded over ranks)",
-                          "frames_per_step_per_gpu": FRAMES, "faces_per_step": faces / args.steps,
+                          "frames_per_step_per_gpu": FRAMES, "ingest": args.ingest, "faces_per_step": faces / args.steps,
                           "gallery_rows": GALLERY_ROWS, "weights": "seeded synthetic",
                           "parallelism": f"frame-shard x{world} + gallery row-shard"},
                "per_face_latency_ms": round(dt / max(faces / world, 1) * 1e3, 4),

@@ -115,7 +115,7 @@ class FaceAnalysis:
         out["embedding"], out["normed_embedding"] = emb, normed
         return out
 
-    def detect_embed_slots(self, frames, det_stream=None):
+    def detect_embed_slots(self, frames, det_stream=None, ready_event=None):
         """Sync-free form for streaming/serving: every frame owns ``cap_o`` face slots.
 
         frames: uint8 [N,H,W,3] BGR on the device.  Returns device tensors only (no host sync):
@@ -126,11 +126,14 @@ class FaceAnalysis:
         wait for the detector through an event, but the detector does NOT wait for work already queued on the
         current stream, so batch i+1's cascade (latency-bound, leaves CU slots idle) runs beside batch i's embed
         convs (MFMA-bound).  The caller guarantees ``frames`` is complete before this call is made (it is when the
-        frames were produced on ``det_stream`` or synchronised earlier)."""
+        frames were produced on ``det_stream`` or synchronised earlier) or passes ``ready_event`` (e.g. the event of
+        ``FrameIngest.upload``), which the detector's stream waits for."""
         if self.det is None:
             raise _lib.FrError("FaceAnalysis.prepare() has not been called")
         N, H, W, _ = frames.shape
         cur = torch.cuda.current_stream(self.device)
+        if ready_event is not None:
+            (det_stream if det_stream is not None else cur).wait_event(ready_event)
         if det_stream is None:
             boxes, scores, kps, counts = self.det.detect_batch(frames)
             kps = kps.contiguous()

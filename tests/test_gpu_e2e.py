@@ -201,3 +201,30 @@ def test_detector_is_bit_stable_beside_the_embedder(app):
             valid = (torch.arange(cap, device="cuda")[None, :] < w[3][:, None]).reshape(-1)
             for a, b in zip(w[:3], g[:3]):
                 assert torch.equal(a.reshape(valid.numel(), -1)[valid], b.reshape(valid.numel(), -1)[valid]), rep
+
+
+def test_frame_ingest_ring_feeds_the_pipeline(app):
+    """Pinned ring -> copy stream -> detector waits on the upload event only."""
+    from make_golden import synth_frame
+    from facerecognition_infrenceengine_amd.ingest import FrameIngest
+    ing = FrameIngest(2, 240, 320, "cuda:0", depth=2)
+    sets = [np.ascontiguousarray(np.stack([synth_frame(240, 320, s + k) for s in (10, 20)])) for k in range(4)]
+    want = [app.detect_embed_slots(torch.from_numpy(f).cuda()) for f in sets]
+    torch.cuda.synchronize()
+    s_det, s_emb = torch.cuda.Stream(), torch.cuda.Stream()
+    got = []
+    with torch.cuda.stream(s_emb):
+        for k, f in enumerate(sets):                        # 4 batches through a 2-slot ring: slots are reused
+            if k >= ing.depth:
+                got[k - ing.depth]["counts"].cpu()          # the caller owns host-buffer reuse: batch k-2 is done
+            ing.host_buffer(k)[...] = f
+            frames, ready = ing.upload(k)
+            got.append(app.detect_embed_slots(frames, det_stream=s_det, ready_event=ready))
+            ing.release(k)
+    torch.cuda.synchronize()
+    for w, g in zip(want, got):
+        assert torch.equal(w["counts"], g["counts"]) and int(w["counts"].sum()) > 0
+        cap = w["bbox"].shape[1]
+        valid = (torch.arange(cap, device="cuda")[None, :] < w["counts"][:, None]).reshape(-1)
+        for k in ("bbox", "det_score", "embedding"):
+            assert torch.equal(w[k].reshape(valid.numel(), -1)[valid], g[k].reshape(valid.numel(), -1)[valid]), k
