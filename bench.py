@@ -19,6 +19,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The step runs on 2 x (detector, embedder, pyramid side) streams + a copy stream.  The HIP runtime maps streams onto
+# 4 hardware queues by default; streams that share a queue serialise (measured: 2 pipes on 4 queues = 20.2 ms/step,
+# on 8 queues = 17.5 ms).  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -86,6 +90,7 @@ def main():
     ap.add_argument("--ingest", default="resident", choices=["resident", "pinned"],
                     help="resident: frames already in HBM (the headline metric); pinned: every step's frames cross "
                          "PCIe from a pinned host ring on a copy stream (reported in DESIGN.md, never the headline)")
+    ap.add_argument("--pipes", type=int, default=2, help="independent (detector, embedder) stream pairs, used round-robin")
     ap.add_argument("--prio", default="none", choices=["none", "det", "emb"], help="stream given high priority")
     ap.add_argument("--one-stream", action="store_true", help="detector and embedder on one stream (no overlap)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
@@ -138,9 +143,11 @@ def main():
     # two HIP streams: the detector cascade of step i+1 (latency-bound) runs beside the embed convs of step i
     # (MFMA-bound); align/embed/match of a step wait for its own detector through an event
     two = not args.one_stream
-    s_det = torch.cuda.Stream(device=device, priority=-1 if args.prio == "det" else 0) if two else None
-    s_emb = (torch.cuda.Stream(device=device, priority=-1 if args.prio == "emb" else 0) if two
-             else torch.cuda.current_stream(device))
+    pipes = []
+    for _ in range(args.pipes if two else 1):
+        pipes.append((torch.cuda.Stream(device=device, priority=-1 if args.prio == "det" else 0) if two else None,
+                      torch.cuda.Stream(device=device, priority=-1 if args.prio == "emb" else 0) if two
+                      else torch.cuda.current_stream(device)))
 
     # ids leave the device through pinned host buffers + an event: a pageable .cpu() drains both streams
     q_rows = FRAMES * FACES_PER_FRAME
@@ -152,6 +159,7 @@ def main():
         """One step, enqueued without any host synchronisation: fixed per-frame face slots, device-side counts,
         asynchronous copy of the ids / decisions / counts to pinned host memory."""
         host = pinned[i % args.depth]
+        s_det, s_emb = pipes[i % len(pipes)]
         with torch.cuda.stream(s_emb):
             if ingest is not None:          # PCIe-inclusive variant: pinned host ring -> device on a copy stream
                 frames, ready = ingest.upload(i)
@@ -166,7 +174,7 @@ def main():
             host["counts"].copy_(r["counts"], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(s_emb)
-        return host, ev, (idx, dec, r)
+        return host, ev, (idx, dec, r, s_emb)
 
     def fetch(pending):
         """ids on the host = end of the step; faces = detected faces (slots beyond a frame's count are ignored)."""

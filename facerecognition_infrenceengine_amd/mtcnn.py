@@ -127,7 +127,7 @@ class MTCNNHIP:
         self.minsize, self.factor, self.thresholds = minsize, factor, tuple(float(t) for t in thresholds)
         self.cap_scale, self.keep_scale, self.cap_p, self.cap_r, self.cap_o = cap_scale, keep_scale, cap_p, cap_r, cap_o
         assert cap_scale <= 4096 and cap_p <= 1024 and cap_r <= 1024 and cap_o <= 1024
-        self._side = None
+        self._sides = {}
         self._one_stream = os.environ.get("FR_DET_ONE_STREAM") == "1"      # profiling: per-kernel times add up
         d = self.device
         p, r, o = ({k: v.detach().float().cpu() for k, v in s.items()} for s in (pstate, rstate, ostate))
@@ -235,9 +235,9 @@ class MTCNNHIP:
             # Level 0 holds half of the pyramid's pixels; the remaining levels are small launches that cannot fill
             # 256 CUs on their own, so they run on a second HIP stream beside level 0 (joined before the NMS).
             main = torch.cuda.current_stream()
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device)
-            side = self._side
+            side = self._sides.get(main.cuda_stream)          # one side stream per caller stream: independent
+            if side is None:                                  # pipelines (bench --pipes) do not couple through it
+                side = self._sides[main.cuda_stream] = torch.cuda.Stream(device=self.device)
             side.wait_stream(main)
             for li, s in enumerate(scales):
                 with torch.cuda.stream(main if li == 0 or trace is not None or self._one_stream else side):

@@ -13,7 +13,7 @@ crops = (torch.rand((256, 112, 112, 8), device=dev) * 2 - 1).half()
 crops[..., 3:] = 0
 sa, sb, sc = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
 import copy
-det2 = copy.copy(app.det); det2._side = None      # own side stream
+det2 = copy.copy(app.det); det2._sides = {}    # own side streams
 
 def timeit(fn, n=20):
     for _ in range(2):
