@@ -95,7 +95,15 @@ def main():
     ap.add_argument("--one-stream", action="store_true", help="detector and embedder on one stream (no overlap)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3"],
+                    help="BASELINE.json config: C2 (default, the headline: 64x1080p, 4 faces/frame, 10k rows); C1 (1 x "
+                         "640x480, 1 face, 100 rows) and C3 (8 x 4K, 16 faces/frame) are side measurements for DESIGN.md")
     args = ap.parse_args()
+    global FRAMES, H, W, FACES_PER_FRAME, GALLERY_ROWS
+    if args.workload == "C1":
+        FRAMES, H, W, FACES_PER_FRAME, GALLERY_ROWS = 1, 480, 640, 1, 100
+    elif args.workload == "C3":
+        FRAMES, H, W, FACES_PER_FRAME = 8, 2160, 3840, 16
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -250,12 +258,13 @@ def main():
                 "algorithmic_gflop_per_launch": round(flops / calls / 1e9, 3)}
 
     if rank == 0:
-        out = {"metric": "faces/sec end-to-end @1080p", "value": round(faces / dt, 1), "unit": "faces/s",
+        out = {"metric": "faces/sec end-to-end @1080p" if args.workload == "C2" else f"faces/sec end-to-end @{H}p", "value": round(faces / dt, 1), "unit": "faces/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-               "config": {"workload": "C2: 64x1080p synthetic frames/GPU, MTCNN full pyramid (caps 512/64/4), "
-                                      "ArcFace r100 f16 embed, 10k-row cosine gallery (row-sharded over ranks)",
+               "config": {"workload": f"{args.workload}: {FRAMES}x{H}p synthetic frames/GPU, MTCNN full pyramid (caps "
+                                      f"512/64/{FACES_PER_FRAME}), ArcFace r100 f16 embed, {GALLERY_ROWS}-row cosine "
+                                      "gallery (row-sharded over ranks)",
                           "frames_per_step_per_gpu": FRAMES, "ingest": args.ingest, "faces_per_step": faces / args.steps,
                           "gallery_rows": GALLERY_ROWS, "weights": "seeded synthetic",
                           "parallelism": f"frame-shard x{world} + gallery row-shard"},
