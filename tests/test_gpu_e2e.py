@@ -228,3 +228,22 @@ def test_frame_ingest_ring_feeds_the_pipeline(app):
         valid = (torch.arange(cap, device="cuda")[None, :] < w["counts"][:, None]).reshape(-1)
         for k in ("bbox", "det_score", "embedding"):
             assert torch.equal(w[k].reshape(valid.numel(), -1)[valid], g[k].reshape(valid.numel(), -1)[valid]), k
+
+
+def test_graph_replay_equals_eager(app):
+    """enable_graphs(): the captured slot pipeline gives the same Face lists as the eager path, call after call."""
+    from make_golden import synth_frame
+    frames = [synth_frame(240, 320, s) for s in (4, 5, 6)]
+    eager = [app.get(f) for f in frames]
+    try:
+        app.enable_graphs(True)
+        for _ in range(2):
+            for f, want in zip(frames, eager):
+                got = app.get(f)
+                assert len(got) == len(want) and len(got) >= 1
+                for a, b in zip(want, got):
+                    assert np.array_equal(a.bbox, b.bbox) and np.array_equal(a.kps, b.kps)
+                    assert a.det_score == b.det_score and np.array_equal(a.embedding, b.embedding)
+                    assert np.array_equal(a.normed_embedding, b.normed_embedding)
+    finally:
+        app.enable_graphs(False)

@@ -11,7 +11,8 @@ with warnings.catch_warnings():
 rng = np.random.default_rng(1)
 G = rng.standard_normal((100, 512)).astype(np.float32)
 m = GalleryMatcher("cuda:0"); m.set_rows(list(range(100)), G)
-for hw in ((480, 640), (1080, 1920)):
+for graphs, hw in ((False, (480, 640)), (False, (1080, 1920)), (True, (480, 640)), (True, (1080, 1920))):
+    app.enable_graphs(graphs)
     fr = synth_frame(hw[0], hw[1], 0)
     for _ in range(3):
         faces = app.get(fr)
@@ -22,4 +23,4 @@ for hw in ((480, 640), (1080, 1920)):
         ids, score, idx = m.match(np.stack([f.normed_embedding for f in faces]))
         ts.append(time.perf_counter() - t0)
     ts = np.asarray(ts) * 1e3
-    print(f"{hw}: {len(faces)} faces  get+match p50 {np.percentile(ts,50):.2f} ms  p95 {np.percentile(ts,95):.2f} ms  -> {np.percentile(ts,50)/max(len(faces),1):.3f} ms/face")
+    print(f"graphs={graphs} {hw}: {len(faces)} faces  get+match p50 {np.percentile(ts,50):.2f} ms  p95 {np.percentile(ts,95):.2f} ms  -> {np.percentile(ts,50)/max(len(faces),1):.3f} ms/face")
