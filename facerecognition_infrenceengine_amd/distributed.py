@@ -63,10 +63,16 @@ class ShardedGalleryMatcher:
         # (2) scan the local shard for every gathered query (padding rows included: fixed shape)
         flat = allq[:, :self.q_max].reshape(self.world * self.q_max, self.dim)
         idx, score = self.local_scan(flat)
-        # (3) gather the per-shard candidates and reduce those of the local queries
-        pair = torch.stack([score.to(torch.float64), idx.to(torch.float64)], dim=1).contiguous()
-        allp = torch.empty((self.world * pair.shape[0], 2), dtype=torch.float64, device=dev)
+        # (3) gather the per-shard candidates and reduce those of the local queries.  (score, row) travel as raw
+        # bits in ONE int32 [n,3] tensor: bit copies only, no float conversion kernels in the exchange
+        n = score.shape[0]
+        pair = torch.empty((n, 3), dtype=torch.int32, device=dev)
+        pair[:, 0] = score.contiguous().view(torch.int32)
+        pair[:, 1:] = idx.contiguous().view(torch.int32).view(n, 2)
+        allp = torch.empty((self.world * n, 3), dtype=torch.int32, device=dev)
         dist.all_gather_into_tensor(allp, pair, group=self.group)
-        allp = allp.view(self.world, pair.shape[0], 2)
-        mine = allp[:, self.rank * self.q_max:self.rank * self.q_max + F]
-        return reduce_candidates(mine[..., 0].to(torch.float32), mine[..., 1].to(torch.int64))
+        mine = allp.view(self.world, n, 3)[:, self.rank * self.q_max:self.rank * self.q_max + F]
+        sc = torch.empty((self.world, F), dtype=torch.int32, device=dev).copy_(mine[..., 0]).view(torch.float32)
+        ix = torch.empty((self.world, F, 2), dtype=torch.int32, device=dev).copy_(mine[..., 1:]).view(torch.int64)
+        ix = ix.reshape(self.world, F)
+        return reduce_candidates(sc, ix)
