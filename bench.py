@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--ingest", default="resident", choices=["resident", "pinned"],
                     help="resident: frames already in HBM (the headline metric); pinned: every step's frames cross "
                          "PCIe from a pinned host ring on a copy stream (reported in DESIGN.md, never the headline)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="with one rank: still run the two all-gathers of the sharded match over RCCL (rehearsal)")
     ap.add_argument("--pipes", type=int, default=2, help="independent (detector, embedder) stream pairs, used round-robin")
     ap.add_argument("--prio", default="none", choices=["none", "det", "emb"], help="stream given high priority")
     ap.add_argument("--one-stream", action="store_true", help="detector and embedder on one stream (no overlap)")
@@ -114,6 +116,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
+    if world == 1 and (args.force_exchange or os.environ.get("FR_INIT_PG") == "1"):           # rehearsal: the N > 1 code path (RCCL collectives) with one rank
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -136,7 +141,8 @@ def main():
     gm = GalleryMatcher(device)
     gm.set_rows(range(lo, hi), G[lo:hi].contiguous(), normalise=True)
     q_max = FRAMES * FACES_PER_FRAME
-    sharded = ShardedGalleryMatcher(lambda Q: gm.match_device(Q, renormalise=True, row_offset=lo), q_max)
+    sharded = ShardedGalleryMatcher(lambda Q: gm.match_device(Q, renormalise=True, row_offset=lo), q_max,
+                                    force_exchange=args.force_exchange)
 
     nbatch = min(max(args.steps, 1), 3)
     batches = [synth_frames(FRAMES, H, W, rank * 1000 + i, device) for i in range(nbatch)]
@@ -205,7 +211,7 @@ def main():
         return n
 
     def sync():
-        if world > 1:
+        if world > 1 or args.force_exchange:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -275,7 +281,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_frames, GALLERY_ROWS)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_exchange:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -40,8 +40,10 @@ def reduce_candidates(scores, idx):
 
 
 class ShardedGalleryMatcher:
-    def __init__(self, local_scan, q_max, dim=512, group=None):
+    def __init__(self, local_scan, q_max, dim=512, group=None, force_exchange=False):
+        """``force_exchange``: run both collectives even with one rank (rehearses the RCCL path on a 1-GPU box)."""
         self.local_scan, self.q_max, self.dim, self.group = local_scan, q_max, dim, group
+        self.force_exchange = force_exchange
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
@@ -50,13 +52,13 @@ class ShardedGalleryMatcher:
         Returns (idx i64[F_local] global rows, score f32[F_local]) for the local queries."""
         F = Q.shape[0]
         assert F <= self.q_max, "more local queries than q_max"
-        if self.world == 1:
+        if self.world == 1 and not self.force_exchange:
             return self.local_scan(Q)
         dev = Q.device
         # (1) gather queries; the count rides in an extra row so it stays ONE collective
         send = torch.zeros((self.q_max + 1, self.dim), dtype=torch.float32, device=dev)
         send[:F] = Q
-        send[self.q_max, 0] = float(F)
+        send[self.q_max:, :1].fill_(float(F))     # (a scalar __setitem__ copies from the host and SYNCHRONISES)
         allq = torch.empty((self.world * (self.q_max + 1), self.dim), dtype=torch.float32, device=dev)
         dist.all_gather_into_tensor(allq, send, group=self.group)      # concatenated along dim 0
         allq = allq.view(self.world, self.q_max + 1, self.dim)
