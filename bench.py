@@ -21,8 +21,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # The step runs on 2 x (detector, embedder, pyramid side) streams + a copy stream.  The HIP runtime maps streams onto
 # 4 hardware queues by default; streams that share a queue serialise (measured: 2 pipes on 4 queues = 20.2 ms/step,
-# on 8 queues = 17.5 ms).  Must be set before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# on 8 queues = 17.5 ms; with RCCL's own streams beside them 8 queues alias again: 19.0 ms, 12 or 16 queues: 17.9 ms).
+# Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
