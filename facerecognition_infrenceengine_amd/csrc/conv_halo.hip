@@ -389,7 +389,7 @@ int fr_conv_halo_try(const fr_conv_args* a, hipStream_t s) {
     int TH;
     if (a->H == 14 && a->Cout % 128 == 0) TH = 14;
     else if (a->H == 28 && a->Cout % 128 == 0) TH = 7;
-    else if (a->H == 56 && a->Cin == 64 && a->Cout == 64) TH = 4;        // single-chunk variants (one halo buffer)
+    else if (a->H == 56 && a->Cin == 64) TH = 4;                         // single-chunk variants (one halo buffer)
     else if (a->H == 112 && a->Cin == 64 && a->Cout == 64) TH = 2;
     else return 0;
     if ((int64_t)a->B * a->H * a->W * a->Cin * 2 >= (1ll << 31) || (int64_t)a->Cout * 9 * a->Cin * 2 >= (1ll << 31)) return 0;

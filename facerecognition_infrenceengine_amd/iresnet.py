@@ -136,7 +136,7 @@ class IResNetHIP:
             if c.k == 3 and c.stride == 1 and H == W and partial is None and c.cin % 64 == 0:
                 if H in (14, 28) and c.cout % 128 == 0:          # lean variant: BN = 128, two blocks per CU
                     halo = "conv_halo_kernel<2, 13, %d, 1, 4, false, true, 4>" % (256 if H == 14 else 320)
-                elif H == 56 and c.cin == 64 and c.cout == 64:
+                elif H == 56 and c.cin == 64:
                     halo = "conv_halo_kernel<1, 14, 384, 1, 4, false, false, 4>"
                 elif H == 112 and c.cin == 64 and c.cout == 64:
                     halo = "conv_halo_kernel<1, 14, 512, 1, 4, false, false, 4>"
