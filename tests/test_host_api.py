@@ -47,6 +47,47 @@ def test_sync_picks_up_updates_and_evicts():
     assert list(m.get_embeddings_for_company("c1")[0]) == ["e0", "e2", "e_new", "v0"]
 
 
+def test_device_slab_bookkeeping_uploads_only_changed_rows(monkeypatch):
+    """SURVEY.md 8f row 2, host half (no GPU): which rows travel / which slots are freed on each sync."""
+    from facerecognition_infrenceengine_amd import gallery
+
+    class FakeSlab:
+        def __init__(self, device, capacity=0):
+            self.log, self.slot_of, self.generation = [], {}, 0
+        def upsert(self, ids, rows, normalise=False):
+            self.log.append(("upsert", list(ids)))
+            assert not normalise and np.allclose(np.linalg.norm(rows, axis=1), 1, atol=1e-6)
+            for i in ids:
+                if i not in self.slot_of:
+                    self.slot_of[i] = len(self.slot_of); self.generation += 1
+        def remove(self, ids):
+            self.log.append(("remove", sorted(ids)))
+            for i in ids:
+                self.slot_of.pop(i, None)
+            self.generation += 1
+        def view(self, ids):
+            v = type("V", (), {})(); v.ids, v.generation = list(ids), self.generation
+            return v
+
+    monkeypatch.setattr(gallery, "DeviceGallery", FakeSlab)
+    s = _store()
+    m = EmbeddingManager(store=s)
+    v, meta = m.get_matcher_for_company("c1")
+    assert v.ids == ["e0", "e1", "e2", "v0"] and list(meta) == v.ids
+    assert m._gallery.log == [("upsert", ["e0", "e1", "e2", "e3", "e4", "v0"])]
+    assert m.get_matcher_for_company("c1")[0] is v                           # cached until the next sync
+    time.sleep(0.01)
+    s.add_employee("e_new", "c1", np.ones(512), name="New")
+    s.employees[1]["status"] = "inactive"
+    m.force_sync()
+    v2, _ = m.get_matcher_for_company("c1")
+    assert v2.ids == ["e0", "e2", "e_new", "v0"]
+    assert m._gallery.log[1:] == [("remove", ["e1"]), ("upsert", ["e_new"])]  # nothing else travelled
+    m.force_sync()
+    m.get_matcher_for_company("c1")
+    assert len(m._gallery.log) == 3                                          # idle sync: no device traffic
+
+
 def test_requires_injected_store():
     with pytest.raises(ValueError):
         EmbeddingManager("mongodb://example", "db")
