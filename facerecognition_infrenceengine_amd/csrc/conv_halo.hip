@@ -63,7 +63,11 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BN = 16 * NA * WN;
     constexpr int WP = 8 / WN;
-    constexpr int PT = (NPT + WP - 1) / WP;
+    // SPLIT (lean 196-pixel tiles): 13 pixel tiles over 4 pixel groups used to be 4+4+4+(1 real + 3 padding) tiles,
+    // i.e. 16 MFMA tiles per wave for 12.25 useful.  Now every wave owns 3 pixel tiles x 64 couts and the 13th pixel
+    // tile is shared by cout: wave (wn, wp) computes its couts [wn*64 + wp*16, +16) -> 13 MFMA tiles per wave.
+    constexpr bool SPLIT = LEAN && WN == 2 && NPT == 13 && NA == 4;
+    constexpr int PT = SPLIT ? 3 : (NPT + WP - 1) / WP;
     constexpr int NWI = BN / 64;                      // weight LDS-DMA instructions per thread per step
     constexpr int NXI = XROWS / 64;                   // halo LDS-DMA instructions per thread per chunk
     unsigned long long tA = 0, tB = 0, tC = 0, tD = 0;
@@ -146,7 +150,19 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
         kbs[j] = kb;
     }
 
+    int hoffx = 0, kbx = 0;      // SPLIT: the shared 13th pixel tile
+    if constexpr (SPLIT) {
+        const int px = 12 * 16 + fr;
+        if (px < p.TH * p.W) {
+            const int oy = px / p.W, ox = px - oy * p.W;
+            const int hb = oy * HW + ox;
+            hoffx = hb * (HK * 2);
+            kbx = hb - 2 * oy;
+        }
+    }
+
     float4v acc[NA][PT];
+    float4v accx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NA; ++i)
 #pragma unroll
@@ -158,6 +174,16 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
     //   mid:  lgkmcnt(0), counted vmcnt, barrier: W(q+1) landed, W(q)'s buffer free
     //         issue W(q+2) [+ next halo] | read (a0,b0)(q+1)    | MFMA half 1 (q)
     int4v a0[NA], b0[PT], a1[NA], b1[PT];       // 8 halves each, kept as 4 dwords (no per-element repacking)
+    int4v ax0 = {0, 0, 0, 0}, bx0 = {0, 0, 0, 0}, ax1 = {0, 0, 0, 0}, bx1 = {0, 0, 0, 0};   // SPLIT: 13th tile operands
+    auto read_x = [&](int4v& ax, int4v& bx, int q, int c, int toff, int kh, int kk) {
+        // A: this wave's 16-cout group of the shared tile (re-read from LDS: a register select by wp would be dynamic)
+        const half_t* wl = ws + (q & 1) * BN * HK + (wn * NA * 16) * HK;
+        const int row = wp * 16 + fr;
+        ax = *reinterpret_cast<const int4v*>(wl + row * HK + (((kk * 4 + fq) ^ (row & 7)) << 3));
+        const char* xl = reinterpret_cast<const char*>(xs + (c & (NXBUF - 1)) * XROWS * HK) + toff * (HK * 2);
+        const int key = (kbx + toff - 2 * kh) & 7;
+        bx = *reinterpret_cast<const int4v*>(xl + hoffx + (((kk * 4 + fq) ^ key) << 4));
+    };
     auto read_frags = [&](int4v (&a)[NA], int4v (&b)[PT], int q, int c, int toff, int kh, int kk) {
         const half_t* wl = ws + (q & 1) * BN * HK + (wn * NA * 16) * HK;
         const char* xl = reinterpret_cast<const char*>(xs + (c & (NXBUF - 1)) * XROWS * HK) + toff * (HK * 2);   // scalar part
@@ -203,9 +229,15 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
             if (q + 1 < nq) issue_w(q + 1);
             STAMP(t3);
             read_frags(a0, b0, q, c, toff, kh, 0);
+            if constexpr (SPLIT) read_x(ax0, bx0, q, c, toff, kh, 0);
             mfma_all(a0, b0);
+            if constexpr (SPLIT)
+                accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ax0), __builtin_bit_cast(half8, bx0), accx, 0, 0, 0);
             read_frags(a1, b1, q, c, toff, kh, 1);
+            if constexpr (SPLIT) read_x(ax1, bx1, q, c, toff, kh, 1);
             mfma_all(a1, b1);
+            if constexpr (SPLIT)
+                accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ax1), __builtin_bit_cast(half8, bx1), accx, 0, 0, 0);
             STAMP(t4);
             ++tap; ++kw; ++toff;
             if (kw == 3) { kw = 0; toff += HW - 3; ++kh; }
@@ -312,10 +344,7 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
         }
         __syncthreads();
     }
-#pragma unroll
-    for (int j = 0; j < PT; ++j) {
-        const int px = (wp * PT + j) * 16 + fr;
-        if (px >= npx) continue;
+    auto bias_sel = [&](int px) {
         int bsel = 0;
         if (p.bias_mode == 1) {
             const int oy = px / p.W, ox = px - oy * p.W, ho = y0 + oy;
@@ -323,25 +352,35 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
             const int cc = ox == 0 ? 0 : (ox == p.W - 1 ? 2 : 1);
             bsel = (rc * 3 + cc) * p.Cout;
         }
+        return bsel;
+    };
+    auto finish = [&](float4v v, int px, int col, int bsel) {       // bias -> PReLU -> + residual -> f16, in place in LDS
+        const int co = cout0 + col;
+        if (p.bias) v += *reinterpret_cast<const float4v*>(p.bias + bsel + co);
+        if (p.slope) {
+            const float4v sv = *reinterpret_cast<const float4v*>(p.slope + co);
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int col = wn * NA * 16 + i * 16 + fq * 4;
-            const int co = cout0 + col;
-            float4v v = acc[i][j];
-            if (p.bias) v += *reinterpret_cast<const float4v*>(p.bias + bsel + co);
-            if (p.slope) {
-                const float4v sv = *reinterpret_cast<const float4v*>(p.slope + co);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * sv[e];
-            }
-            half4* slot = reinterpret_cast<half4*>(ot + px * OP + col);
-            if (p.res) {
-                const half4 rv = *slot;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-            }
-            *slot = half4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * sv[e];
         }
+        half4* slot = reinterpret_cast<half4*>(ot + px * OP + col);
+        if (p.res) {
+            const half4 rv = *slot;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+        }
+        *slot = half4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    };
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        const int px = (wp * PT + j) * 16 + fr;
+        if (px >= npx) continue;
+        const int bsel = bias_sel(px);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) finish(acc[i][j], px, wn * NA * 16 + i * 16 + fq * 4, bsel);
+    }
+    if constexpr (SPLIT) {
+        const int px = 12 * 16 + fr;
+        if (px < npx) finish(accx, px, wn * NA * 16 + wp * 16 + fq * 4, bias_sel(px));
     }
     __syncthreads();
     for (int e = tid; e < npx * CPR; e += 512) {
