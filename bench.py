@@ -255,8 +255,8 @@ def main():
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
         hits = [v for k, v in rec.items() if k.startswith(dom + " ") and "hbm_bytes_per_launch_corrected" in v]
-        if hits:
-            traffic = hits[0]["hbm_bytes_per_launch_corrected"]
+        if hits:            # the kernel serves several layer shapes: take the one with the most launches
+            traffic = max(hits, key=lambda v: v.get("dispatches", 0))["hbm_bytes_per_launch_corrected"]
     except (OSError, KeyError, ValueError):
         pass
     roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
