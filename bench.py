@@ -237,6 +237,21 @@ def main():
         tsum = tot.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt, faces = float(tmax[0]), float(tsum[1])
 
+    # ---- self-check (outside the timed region): the last pipelined step's ids / decisions / counts, still in their
+    # pinned buffers, must equal a sequential single-stream re-run of the same batch (cross-stream hazards are silent)
+    if args.steps > 0:
+        last = args.steps - 1
+        host = pinned[last % args.depth]
+        r = app.detect_embed_slots(batches[last % nbatch])
+        idx2, score2 = sharded.match(r["normed_embedding"])
+        dec2 = gm.decide_device(idx2, score2, 0.4)
+        cnt2 = r["counts"].cpu()
+        valid = (torch.arange(FACES_PER_FRAME)[None, :] < cnt2[:, None]).reshape(-1)      # empty slots are undefined
+        same = (torch.equal(cnt2, host["counts"]) and torch.equal(idx2.cpu()[valid], host["idx"][valid])
+                and torch.equal(dec2.cpu()[valid], host["dec"][valid]))
+        if not same:
+            raise SystemExit(f"rank {rank}: pipelined step {last} disagrees with its sequential re-run - results invalid")
+
     # ---- instrumented pass (outside the timed region): HIP events around every conv launch
     app.rec.profile = []
     r = app.detect_embed_slots(batches[0])
@@ -278,6 +293,7 @@ def main():
                "per_face_latency_ms": round(dt / max(faces / world, 1) * 1e3, 4),
                "p50_step_ms": round(float(np.percentile(step_ms, 50)), 3),
                "p50_face_latency_ms": round(float(np.percentile(step_ms, 50)) / max(faces / world / args.steps, 1), 4),
+               "self_check": "last pipelined step == sequential single-stream re-run (ids, decisions, counts)",
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_frames, GALLERY_ROWS)
