@@ -38,3 +38,17 @@ def test_invalid_arguments_return_error_not_crash():
         lib.fr_gallery_match_f32(None, None, 1, 10, 256, 0, None, None, None, 0, None)
     with pytest.raises(_lib.FrError):
         lib.fr_l2norm_rows_f32(None, None, 4, 7, None)
+    with pytest.raises(_lib.FrError, match="null view"):
+        lib.fr_gallery_match_view_f32(None, None, None, 1, 10, 512, None, None, None, 0, None)
+    with pytest.raises(_lib.FrError, match="D must be 512"):
+        import ctypes as C
+        lib.fr_gallery_match_view_f32(None, None, C.c_void_p(16), 1, 10, 128, None, None, None, 0, None)
+    with pytest.raises(_lib.FrError, match="D must be 512"):
+        lib.fr_gallery_update_rows_f32(None, None, None, 3, 64, 0, None)
+    with pytest.raises(_lib.FrError, match="null pointer"):
+        lib.fr_gallery_update_rows_f32(None, None, None, 3, 512, 0, None)
+    assert lib.fr_gallery_update_rows_f32(None, None, None, 0, 512, 0, None) == 0        # nothing to do: no pointers read
+    with pytest.raises(_lib.FrError, match="unknown layer"):
+        import ctypes as C
+        one = C.c_void_p(16)          # never dereferenced: the layer id is rejected first
+        lib.fr_dconv_mfma_f32(99, one, one, one, None, one, 1, 8, 8, None, None, None, 0, 0, None)
