@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--ingest", default="resident", choices=["resident", "pinned"],
                     help="resident: frames already in HBM (the headline metric); pinned: every step's frames cross "
                          "PCIe from a pinned host ring on a copy stream (reported in DESIGN.md, never the headline)")
+    ap.add_argument("--gallery-rows", type=int, default=0, help="override the gallery size (C4: 1 000 000 rows in total)")
+    ap.add_argument("--gallery", default="f32", choices=["f32", "f16"],
+                    help="f16: coarse scan of an f16 copy on the f16 matrix cores + exact f32 re-rank of the top 4")
     ap.add_argument("--force-exchange", action="store_true",
                     help="with one rank: still run the two all-gathers of the sharded match over RCCL (rehearsal)")
     ap.add_argument("--pipes", type=int, default=2, help="independent (detector, embedder) stream pairs, used round-robin")
@@ -107,6 +110,8 @@ def main():
         FRAMES, H, W, FACES_PER_FRAME, GALLERY_ROWS = 1, 480, 640, 1, 100
     elif args.workload == "C3":
         FRAMES, H, W, FACES_PER_FRAME = 8, 2160, 3840, 16
+    if args.gallery_rows:
+        GALLERY_ROWS = args.gallery_rows
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -139,7 +144,7 @@ def main():
     g = torch.Generator(device=device).manual_seed(1)
     G = torch.randn((GALLERY_ROWS, 512), generator=g, device=device)
     lo, hi = shard_rows(GALLERY_ROWS, world, rank)
-    gm = GalleryMatcher(device)
+    gm = GalleryMatcher(device, f16_scan=args.gallery == "f16")
     gm.set_rows(range(lo, hi), G[lo:hi].contiguous(), normalise=True)
     q_max = FRAMES * FACES_PER_FRAME
     sharded = ShardedGalleryMatcher(lambda Q: gm.match_device(Q, renormalise=True, row_offset=lo), q_max,
@@ -289,7 +294,7 @@ def main():
                                       f"512/64/{FACES_PER_FRAME}), ArcFace r100 f16 embed, {GALLERY_ROWS}-row cosine "
                                       "gallery (row-sharded over ranks)",
                           "frames_per_step_per_gpu": FRAMES, "ingest": args.ingest, "faces_per_step": faces / args.steps,
-                          "gallery_rows": GALLERY_ROWS, "weights": "seeded synthetic",
+                          "gallery_rows": GALLERY_ROWS, "gallery_scan": args.gallery, "weights": "seeded synthetic",
                           "parallelism": f"frame-shard x{world} + gallery row-shard"},
                # amortised: wall time / faces.  Batch latency: frames handed to the pipeline -> that batch's ids on the
                # host, with args.depth batches in flight (the throughput setting; --depth 1 --one-stream is the
