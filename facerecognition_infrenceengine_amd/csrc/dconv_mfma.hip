@@ -55,7 +55,7 @@ struct DcCfg {
     static constexpr int NPIX = G * RH * RW;
     static constexpr int TP = (NPIX + 15) / 16;
     static constexpr int PT = (TP + WM - 1) / WM;
-    static constexpr int CS = NTB * 16 + 1;                       // conv-output tile pixel stride (POOL == 2)
+    static constexpr int CS = NTB * 16 + 4;                       // conv-output tile pixel stride (POOL == 2): 16-B rows, bank shift 4
     static constexpr int OUT_FLOATS = POOL == 2 ? NPIX * CS : 0;
     static constexpr int IN_FLOATS = G * IMG > OUT_FLOATS ? G * IMG : OUT_FLOATS;   // the two tiles share LDS
     static constexpr int W_OFF = (IN_FLOATS + 3) / 4 * 4;
@@ -339,36 +339,42 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
                 const int p = (wm * C::PT + t) * 16 + li;
                 if (p >= C::NPIX) continue;
 #pragma unroll
-                for (int i = 0; i < C::NT; ++i) {
-                    float* d = ot + p * C::CS + (wn * C::NT + i) * 16 + kq * 4;
-                    d[0] = acc[i][t][0]; d[1] = acc[i][t][1]; d[2] = acc[i][t][2]; d[3] = acc[i][t][3];
-                }
+                for (int i = 0; i < C::NT; ++i)            // the lane's 4 consecutive channels: one 16-byte LDS store
+                    *reinterpret_cast<float4v*>(ot + p * C::CS + (wn * C::NT + i) * 16 + kq * 4) = acc[i][t];
             }
             __syncthreads();
             const int PH = (a.Ho - PK + 1) / 2 + 1 - ((((a.Ho - PK + 1) / 2) * 2 >= a.Ho) ? 1 : 0);
             const int PW = (a.Wo - PK + 1) / 2 + 1 - ((((a.Wo - PK + 1) / 2) * 2 >= a.Wo) ? 1 : 0);
             constexpr int PRH = RSY / 2, PRW = RSX / 2;     // pooled rows / cols owned by one region
-            constexpr int CG = NTB * 16;
-            for (int e = tid; e < G * PRH * PRW * CG; e += C::NTHR) {
-                const int co = e % CG, pp = e / CG;
+            constexpr int CG = NTB * 16, Q4 = CG / 4;
+            static_assert(COUT % 4 == 0, "pooled layers store 4 channels per thread");
+            // a thread owns (pooled pixel, 4 channels): PK*PK 16-byte LDS reads, no branches - window positions past
+            // the region or the image edge are CLAMPED onto the last valid row / column (a ceil-mode window always
+            // starts inside, so the clamp only repeats a value that is in the window anyway)
+            const int vh = min(RH, a.Ho - y0), vw = min(RW, a.Wo - x0);
+            for (int e = tid; e < G * PRH * PRW * Q4; e += C::NTHR) {
+                const int qd = e % Q4, pp = e / Q4;
                 const int g = pp / (PRH * PRW), q = pp - g * (PRH * PRW);
                 const int pyl = q / PRW, pxl = q - pyl * PRW;
                 const int py = y0 / 2 + pyl, px = x0 / 2 + pxl, n = img0 + g;
-                const int cout = cg * CG + co;
+                const int cout = cg * CG + qd * 4;
                 if (py >= PH || px >= PW || n >= a.B || cout >= COUT) continue;
-                float m = -INFINITY;
+                int ro[PK], cl[PK];
 #pragma unroll
-                for (int dy = 0; dy < PK; ++dy) {
-                    const int cy = 2 * pyl + dy;
-                    if (cy >= RH || y0 + cy >= a.Ho) continue;
+                for (int d = 0; d < PK; ++d) {
+                    ro[d] = (g * RH + min(2 * pyl + d, vh - 1)) * RW;
+                    cl[d] = min(2 * pxl + d, vw - 1);
+                }
+                float4v m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+                for (int dy = 0; dy < PK; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < PK; ++dx) {
-                        const int cx = 2 * pxl + dx;
-                        if (cx >= RW || x0 + cx >= a.Wo) continue;
-                        m = fmaxf(m, ot[(g * RH * RW + cy * RW + cx) * C::CS + co]);
+                        const float4v v = *reinterpret_cast<const float4v*>(ot + (ro[dy] + cl[dx]) * C::CS + qd * 4);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) m[c] = fmaxf(m[c], v[c]);
                     }
-                }
-                a.y[(((int64_t)n * PH + py) * PW + px) * COUT + cout] = m;
+                *reinterpret_cast<float4v*>(a.y + (((int64_t)n * PH + py) * PW + px) * COUT + cout) = m;
             }
         } else if constexpr (NHEAD > 0) {
             float4v hd[C::PT];
