@@ -323,9 +323,13 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
                         const int n = img0;
                         if ((li & 1) == 0 && py < Hp && px < Wp && n < a.B) {
                             float* o = a.y + (((int64_t)n * Hp + py) * Wp + px) * COUT;
+                            if constexpr (COUT % 4 == 0) {       // the lane's 4 consecutive channels: one 16-byte store
+                                if (coW + i * 16 < COUT) *reinterpret_cast<float4v*>(o + coW + i * 16) = v;
+                            } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (coW + i * 16 + e < COUT) o[coW + i * 16 + e] = v[e];
+                                for (int e = 0; e < 4; ++e)
+                                    if (coW + i * 16 + e < COUT) o[coW + i * 16 + e] = v[e];
+                            }
                         }
                     }
                 }
