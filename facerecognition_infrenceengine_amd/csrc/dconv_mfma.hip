@@ -521,7 +521,7 @@ extern "C" int fr_dconv_mfma_f32(int layer, const float* x, const float* w, cons
         case 14: FR_REQUIRE(H == 1 && W == 1, "R5 expects 1x1");
                  rc = launch_dc<128, 6, 1, 1, 1, 1, 64, 1, 1, 1, 0, 2, 1, 1, 0, 1, 0>(a, s); break;       // dense5_1|5_2
         case 20: FR_REQUIRE(H == 48 && W == 48, "O1 expects 48x48");                        // conv1 + 3x3/s2 pool -> 23x23
-                 rc = launch_dc<4, 32, 3, 3, 9, 46, 1, 2, 1, 9, 2, 3, 8, 46, 0, 6, 0>(a, s); break;
+                 rc = launch_dc<4, 32, 3, 3, 9, 46, 1, 1, 1, 9, 2, 3, 8, 46, 0, 6, 0>(a, s); break;
         case 21: FR_REQUIRE(H == 23 && W == 23, "O2 expects 23x23");                        // conv2 + 3x3/s2 pool -> 10x10
                  rc = launch_dc<32, 64, 3, 3, 7, 21, 1, 4, 1, 3, 2, 3, 6, 20, 0, 1, 0>(a, s); break;
         case 22: FR_REQUIRE(H == 10 && W == 10, "O3 expects 10x10");                        // conv3 + 2x2/s2 pool -> 4x4
