@@ -63,7 +63,6 @@ struct DcCfg {
     static_assert(NTAPS % TG == 0, "TG must divide the tap count");
     static_assert(NTB % WN == 0 && (WN == 1 || WN == 2 || WN == 4), "bad wave split");
     static_assert(POOL != 1 || (RW % 16 == 0 && RH % 2 == 0 && G == 1 && WN == 1 && (RH * RW / 16) % NW == 0), "pool layout");
-    static_assert(RPB == 1 || NSTAGE == 1, "multi-item blocks need resident weights");
     static_assert(CIN % 4 == 0 || SRC == 1, "f32 inputs are read as float4: pad channels to a multiple of 4");
     static_assert(SRC == 0 || CIN == 3, "fused resize feeds a 3-channel layer");
 };
@@ -106,6 +105,27 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
         const float4v* src4 = reinterpret_cast<const float4v*>(wsrc + (int64_t)st * TG * C::CINP * C::CP);
         float4v* dst4 = reinterpret_cast<float4v*>(wl);
         for (int e = tid; e < TG * C::CINP * C::CP / 4; e += C::NTHR) dst4[e] = src4[e];
+    };
+    // tap groups that do not all fit in LDS (NSTAGE > 1) go through registers one stage ahead: the global loads of
+    // stage st+1 fly under the MFMAs of stage st (staging them in place exposed an L2 round trip per stage)
+    constexpr int W4 = TG * C::CINP * C::CP / 4;                 // float4 slots of one stage
+    constexpr int NWPF = C::NSTAGE > 1 ? (W4 + C::NTHR - 1) / C::NTHR : 1;
+    float4v wpf[NWPF];
+    auto load_w = [&](int st) {
+        const float4v* src4 = reinterpret_cast<const float4v*>(wsrc + (int64_t)st * TG * C::CINP * C::CP);
+#pragma unroll
+        for (int u = 0; u < NWPF; ++u) {
+            const int e = tid + u * C::NTHR;
+            wpf[u] = e < W4 ? src4[e] : float4v{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_w = [&]() {
+        float4v* dst4 = reinterpret_cast<float4v*>(wl);
+#pragma unroll
+        for (int u = 0; u < NWPF; ++u) {
+            const int e = tid + u * C::NTHR;
+            if (e < W4) dst4[e] = wpf[u];
+        }
     };
 
     // ---- input tile: global -> registers (issued early, lands under the previous item's MFMAs) -> LDS
@@ -177,6 +197,7 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
 
     if (item0 < nitems) load_tile(item0);
     if (C::NSTAGE == 1) stage_weights(0);
+    else load_w(0);
 
     // ---- per-lane pixel bases (region-relative, the same for every item)
     int base[C::PT];
@@ -237,8 +258,10 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
 
         for (int st = 0; st < C::NSTAGE; ++st) {
             if (C::NSTAGE > 1) {
-                if (st > 0) __syncthreads();
-                stage_weights(st);
+                if (st > 0) __syncthreads();                 // every wave is done with the previous stage's weights
+                store_w();
+                if (st + 1 < C::NSTAGE) load_w(st + 1);
+                else if (more) load_w(0);
             }
             __syncthreads();
             // operands of k step s+1 are read before the MFMAs of step s are issued (the compiler's own order
@@ -523,7 +546,7 @@ extern "C" int fr_dconv_mfma_f32(int layer, const float* x, const float* w, cons
         case 20: FR_REQUIRE(H == 48 && W == 48, "O1 expects 48x48");                        // conv1 + 3x3/s2 pool -> 23x23
                  rc = launch_dc<4, 32, 3, 3, 9, 46, 1, 1, 1, 9, 2, 3, 8, 46, 0, 6, 0>(a, s); break;
         case 21: FR_REQUIRE(H == 23 && W == 23, "O2 expects 23x23");                        // conv2 + 3x3/s2 pool -> 10x10
-                 rc = launch_dc<32, 64, 3, 3, 7, 21, 1, 4, 1, 3, 2, 3, 6, 20, 0, 1, 0>(a, s); break;
+                 rc = launch_dc<32, 64, 3, 3, 11, 21, 1, 2, 1, 3, 2, 3, 10, 20, 0, 1, 0>(a, s); break;   // 2 regions of 11 conv rows x 2 cout groups
         case 22: FR_REQUIRE(H == 10 && W == 10, "O3 expects 10x10");                        // conv3 + 2x2/s2 pool -> 4x4
                  rc = launch_dc<64, 64, 3, 3, 8, 8, 1, 4, 1, 1, 2, 2, 8, 8, 0, 1, 0>(a, s); break;
         case 23: FR_REQUIRE(H == 4 && W == 4, "O4 expects 4x4");

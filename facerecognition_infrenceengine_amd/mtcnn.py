@@ -64,7 +64,7 @@ class _DConv:
 MFMA_LAYERS = {0: (3, 12, 3, 3, 1), 1: (12, 16, 3, 3, 1), 2: (16, 32, 3, 3, 2),
                10: (4, 28, 3, 3, 2), 11: (28, 48, 3, 3, 3), 12: (48, 64, 2, 2, 4), 13: (64, 128, 3, 3, 4),
                14: (128, 6, 1, 1, 1),
-               20: (4, 32, 3, 3, 1), 21: (32, 64, 3, 3, 4), 22: (64, 64, 3, 3, 4), 23: (64, 128, 2, 2, 4),
+               20: (4, 32, 3, 3, 1), 21: (32, 64, 3, 3, 2), 22: (64, 64, 3, 3, 4), 23: (64, 128, 2, 2, 4),
                24: (128, 256, 3, 3, 4), 25: (256, 16, 1, 1, 1)}
 
 
