@@ -248,7 +248,8 @@ def main():
     if args.steps > 0:
         last = args.steps - 1
         host = pinned[last % args.depth]
-        r = app.detect_embed_slots(batches[last % nbatch])
+        src = (last % ingest.depth) % nbatch if ingest is not None else last % nbatch     # the batch that step used
+        r = app.detect_embed_slots(batches[src])
         idx2, score2 = sharded.match(r["normed_embedding"])
         dec2 = gm.decide_device(idx2, score2, 0.4)
         cnt2 = r["counts"].cpu()

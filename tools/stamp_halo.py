@@ -6,11 +6,12 @@ st = torch.zeros(4096 * 8 * 8, dtype=torch.int64, device="cuda")
 os.environ["FR_DBG_STAMPS"] = hex(st.data_ptr())
 from tools import bench_conv
 B = 256
-for shape in ((14, 256, 256), (28, 128, 128)):
+for shape in ((14, 256, 256), (28, 128, 128), (56, 64, 64), (112, 64, 64)):
     st.zero_()
     bench_conv.run(B, shape[0], shape[0], shape[1], shape[2], iters=3, tag="stamped")
     torch.cuda.synchronize()
-    nb = (B * 2 if shape[0] == 14 else B * 4)          # lean variant: BN = 128 -> 2 N tiles at Cout = 256
+    nb = {14: B * 2, 28: B * 4, 56: B * 14, 112: B * 56}[shape[0]]   # blocks (stamp slots wrap at 4096)
+    nb = min(nb, 4096)
     d = st.reshape(-1, 8)[: nb * 8, :5].double()
     tot = d.sum(1)
     names = ["wait vmcnt", "barrier", "issue W", "reads+MFMA", "tap bookkeeping / halo reload"]
