@@ -1,17 +1,19 @@
 // 3x3 / stride 1 / pad 1 convolution with an LDS-STAGED INPUT TILE (halo) reused by all nine taps:
-// the IResNet body convs (82 % of the embed FLOPs) at 28x28 and 14x14.  Same math, operand maps and
+// the IResNet body convs (82 % of the embed FLOPs) at 112x112 .. 14x14.  Same math, operand maps and
 // epilogue as conv_mfma.hip; what changes is the traffic: the generic implicit GEMM re-gathers the
 // input tile for every tap (operand fetch = (BN+BM)*128 B per 64-deep K step, measured bound by the
 // L2/Infinity-Cache gather rate), here the input rows + halo of one 64-channel chunk are brought in
 // ONCE per chunk (9 K steps) and only the weight tile streams per step.
 //
-// Tile = 196 output pixels (TH rows x full width W: 14x14 or 7x28) of one image x BN couts
-// (13 MFMA pixel tiles, 94 % useful) ; 512 threads = 8 waves = WN (64 couts each) x WP pixel groups.
-// LDS: input halo chunk [2][320 rows][64 ch] (40 KB each, zero border by out-of-range LDS-DMA),
-// weight tile [2][BN][64] (32 KB each at BN = 256); rows 128 B with 16-B chunk XOR (row & 7).
-// Schedule per K step q = chunk*9 + tap: counted wait -> raw barrier -> issue W(q+1) (LDS-DMA, scalar
-// offset only) and, at tap 0, the next chunk's halo (lands two steps later, vmcnt(5) keeps it in flight
-// across one barrier) -> 2 x (NA A-fragments + PT B-fragments via ds_read_b128) -> 2*NA*PT MFMAs.
+// Tile = TH whole image rows of one image (196 pixels at 14x14 / 7x28, 224 at 4x56 / 2x112) x BN couts;
+// 512 threads = 8 waves = WN (64 couts each) x WP pixel groups.  LDS: halo chunk [NXBUF][XROWS][64 ch]
+// (zero border by out-of-range LDS-DMA), weight tile [2][BN][64]; rows of 128 B with a 16-B chunk XOR.
+// Variants in use (fr_conv_halo_try): LEAN <2,13,256|320,1,4,true> for 14x14 / 28x28 (BN = 128, one halo
+// buffer, <= 128 VGPRs, two blocks per CU, 13th pixel tile shared by cout = SPLIT); single-chunk
+// <1,14,384|512,1,4> for Cin = 64 at 56x56 / 112x112; the pipelined two-halo-buffer schedule
+// (<4|2,13,320,2,2>, one block per CU) is kept behind FR_HALO_LEAN=0.
+// Lean schedule per K step q = chunk*9 + tap: vmcnt(0) -> raw barrier -> issue W(q+1) (LDS-DMA, scalar
+// offset only) -> 2 x (A and B fragments via ds_read_b128, 13 MFMAs); at a chunk end: barrier + halo reload.
 // No gather arithmetic in the loop: per-lane halo bases are fixed, taps are scalar row offsets.
 #include "common.h"
 #include <cstdlib>
