@@ -67,6 +67,7 @@ struct DcCfg {
     static_assert(SRC == 0 || CIN == 3, "fused resize feeds a 3-channel layer");
 };
 
+typedef unsigned long long u64_unaligned __attribute__((aligned(1)));
 struct DLerp { int i0, i1; float w; };
 __device__ __forceinline__ DLerp dlerp_coord(int d, float ratio, int n) {      // == detect_ops.hip lerp_coord
     float f = ((float)d + 0.5f) * ratio - 0.5f;
@@ -89,6 +90,8 @@ template <int CIN, int COUT, int KH, int KW, int RH, int RW, int G, int NTB, int
 __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
     using C = DcCfg<CIN, COUT, KH, KW, RH, RW, G, NTB, WN, TG, POOL, PK, RSY, RSX, NHEAD, RPB, SRC, NW>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned long long dk = 0;
+    DSTAMP(dk);
     float* xin = lds;
     float* wl = lds + C::W_OFF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -132,7 +135,14 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
     constexpr int C4 = C::CINP / 4;
     constexpr int NLOAD = SRC == 1 ? C::IH * C::IW : G * C::IH * C::IW * C4;     // float4 slots of one tile
     constexpr int NPF = (NLOAD + C::NTHR - 1) / C::NTHR;
-    float4v pf[NPF];
+    float4v pf[SRC == 1 ? 1 : NPF];
+    // SRC == 1: the prefetch keeps the RAW source bytes (two 8-byte row pieces per level pixel) and the lerp weights;
+    // conversion + bilinear blend happen in store_tile, AFTER the current tile's MFMAs - doing them in load_tile made
+    // the "prefetch" wait for its own loads (stamps: 11 k cycles per tile in load_tile)
+    unsigned long long rq0[SRC == 1 ? NPF : 1], rq1[SRC == 1 ? NPF : 1];
+    float rwx[SRC == 1 ? NPF : 1], rwy[SRC == 1 ? NPF : 1];
+    int rsh[SRC == 1 ? NPF : 1];                     // 24: x1 = x0 + 1; 0: clamped right border; -1: pixel outside the level
+    int rpb[SRC == 1 ? NPF : 1];                     // pull-back of the two row loads in bits (last frame's last bytes)
     // slot e of the tile -> (image g, pixel iy/ix, channel group c4, LDS offset); decoded on the fly: keeping the
     // decode in registers across tiles cost 3 VGPRs per slot and bought nothing (measured)
     auto slot = [&](int e, int& iy, int& ix, int& g, int& c4, int& l) {
@@ -151,6 +161,10 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
             }
         }
     };
+    // SRC == 1: level -> frame scale factors and frame size, the same for every tile of the launch
+    const float ryr = SRC == 1 ? (float)a.FH / (float)a.H : 0.f, rxr = SRC == 1 ? (float)a.FW / (float)a.W : 0.f;
+    const int frame_bytes = a.FH * a.FW * 3;
+    static_assert(SRC != 1 || G == 1, "fused resize: one frame per tile (block-uniform frame base)");
     auto load_tile = [&](int item) {
         const int zz = item / per_img, rem = item - zz * per_img;
         const int ry = rem / a.regions_x, rx = rem - ry * a.regions_x;
@@ -162,25 +176,30 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
             slot(tid + u * C::NTHR, iy, ix, g, c4, l);
             const int yy = y0 + iy, xx = x0 + ix;
             const int n = img0 + g;
-            if (l >= 0 && n < a.B && yy < a.H && xx < a.W) {
-                if constexpr (SRC == 1) {
-                    const float ryr = (float)a.FH / (float)a.H, rxr = (float)a.FW / (float)a.W;
+            if constexpr (SRC == 1) {
+                rsh[u] = -1; rq0[u] = rq1[u] = 0; rwx[u] = rwy[u] = 0.f; rpb[u] = 0;
+                if (l >= 0 && n < a.B && yy < a.H && xx < a.W) {
                     const DLerp ly = dlerp_coord(yy, ryr, a.FH), lx = dlerp_coord(xx, rxr, a.FW);
-                    const uint8_t* f = a.frames + (int64_t)n * a.FH * a.FW * 3;
-                    const uint8_t* r0 = f + (int64_t)ly.i0 * a.FW * 3;
-                    const uint8_t* r1 = f + (int64_t)ly.i1 * a.FW * 3;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const int ci = 2 - c;                   // BGR -> RGB
-                        const float sv = dbilerp((float)r0[lx.i0 * 3 + ci], (float)r0[lx.i1 * 3 + ci],
-                                                 (float)r1[lx.i0 * 3 + ci], (float)r1[lx.i1 * 3 + ci], lx.w, ly.w);
-                        v[c] = (sv - 127.5f) * 0.0078125f;
-                    }
-                } else {
-                    v = *reinterpret_cast<const float4v*>(a.x + (((int64_t)n * a.H + yy) * a.W + xx) * CIN + c4 * 4);
+                    // both corners of a row are 6 adjacent bytes (BGR BGR): ONE unaligned 8-byte load per source row.
+                    // 32-bit offsets inside the (block-uniform) frame; in the LAST frame the load is pulled back so
+                    // that it never runs past the end of the buffer.  x1 == x0 (clamped right border) re-uses the
+                    // first pixel's bytes.
+                    const uint8_t* fbase = a.frames + (int64_t)n * frame_bytes;
+                    const int lim = n == a.B - 1 ? frame_bytes - 8 : 0x7fffffff;
+                    const int o0 = (ly.i0 * a.FW + lx.i0) * 3, o1 = (ly.i1 * a.FW + lx.i0) * 3;
+                    const int c0 = min(o0, lim), c1 = min(o1, lim);
+                    // raw loads only: any arithmetic on the loaded value here would make the prefetch wait for it
+                    rq0[u] = *reinterpret_cast<const u64_unaligned*>(fbase + c0);
+                    rq1[u] = *reinterpret_cast<const u64_unaligned*>(fbase + c1);
+                    rpb[u] = ((o0 - c0) * 8) | (((o1 - c1) * 8) << 8);
+                    rwx[u] = lx.w; rwy[u] = ly.w;
+                    rsh[u] = lx.i1 == lx.i0 ? 0 : 24;
                 }
+            } else {
+                if (l >= 0 && n < a.B && yy < a.H && xx < a.W)
+                    v = *reinterpret_cast<const float4v*>(a.x + (((int64_t)n * a.H + yy) * a.W + xx) * CIN + c4 * 4);
+                pf[u] = v;
             }
-            pf[u] = v;
         }
     };
     auto store_tile = [&]() {
@@ -190,7 +209,24 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
             slot(tid + u * C::NTHR, iy, ix, g, c4, l);
             if (l >= 0) {
                 float* d = xin + l;
-                d[0] = pf[u][0]; d[1] = pf[u][1]; d[2] = pf[u][2]; d[3] = pf[u][3];
+                if constexpr (SRC == 1) {
+                    float v[3] = {0.f, 0.f, 0.f};
+                    if (rsh[u] >= 0) {
+                        const unsigned long long q0 = rq0[u] >> (rpb[u] & 0xff), q1 = rq1[u] >> (rpb[u] >> 8);
+                        const int sh = rsh[u];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const int ci = 2 - c;                   // BGR -> RGB
+                            const float sv = dbilerp((float)(unsigned)((q0 >> (8 * ci)) & 0xff), (float)(unsigned)((q0 >> (8 * ci + sh)) & 0xff),
+                                                     (float)(unsigned)((q1 >> (8 * ci)) & 0xff), (float)(unsigned)((q1 >> (8 * ci + sh)) & 0xff),
+                                                     rwx[u], rwy[u]);
+                            v[c] = (sv - 127.5f) * 0.0078125f;
+                        }
+                    }
+                    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = 0.f;
+                } else {
+                    d[0] = pf[u][0]; d[1] = pf[u][1]; d[2] = pf[u][2]; d[3] = pf[u][3];
+                }
             }
         }
     };
@@ -243,6 +279,7 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
         const int item = item0 + rr;
         if (item >= nitems) break;
         DSTAMP(d0);
+        if (a.stamps && rr == 0) q01 += d0 - dk;          // block prologue (first tile load, weights) counted once
         const int zz = item / per_img, rem = item - zz * per_img;
         const int ry = rem / a.regions_x, rx = rem - ry * a.regions_x;
         const int y0 = ry * RSY, x0 = rx * RSX, img0 = zz * G;
@@ -516,7 +553,13 @@ extern "C" int fr_dconv_mfma_f32(int layer, const float* x, const float* w, cons
     switch (layer) {
         //                  CIN COUT KH KW RH  RW  G NTB WN TG POOL PK RSY RSX NHEAD RPB SRC
         case 0:  FR_REQUIRE(H >= 3 && W >= 3 && frames, "P1 needs frames and a level of at least 3x3");
-                 rc = launch_dc<3, 12, 3, 3, 16, 32, 1, 1, 1, 9, 1, 2, 16, 32, 0, 1, 1>(a, s); break;     // P-Net conv1 (+resize, PReLU, pool)
+                 { static int v = -1; if (v < 0) { const char* e = getenv("FR_P1_RPB"); v = e ? atoi(e) : 8; }
+                 const bool big = (int64_t)((H - 2 + 15) / 16) * ((W - 2 + 31) / 32) * B >= 8192;
+                 if (big && v == 2) rc = launch_dc<3, 12, 3, 3, 16, 32, 1, 1, 1, 9, 1, 2, 16, 32, 0, 2, 1>(a, s);
+                 else if (big && v == 4) rc = launch_dc<3, 12, 3, 3, 16, 32, 1, 1, 1, 9, 1, 2, 16, 32, 0, 4, 1>(a, s);
+                 else if (big && v == 8) rc = launch_dc<3, 12, 3, 3, 16, 32, 1, 1, 1, 9, 1, 2, 16, 32, 0, 8, 1>(a, s);
+                 else rc = launch_dc<3, 12, 3, 3, 16, 32, 1, 1, 1, 9, 1, 2, 16, 32, 0, 1, 1>(a, s); }
+                 break;                                                                                   // P-Net conv1 (+resize, PReLU, pool)
         case 1:  FR_REQUIRE(H >= 3 && W >= 3, "P2 input too small");
                  // small pyramid levels have too few tiles to fill 256 CUs: multi-tile blocks only add latency there
                  if ((int64_t)((H - 2 + 7) / 8) * ((W - 2 + 31) / 32) * B < 8192)
