@@ -213,13 +213,16 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
                     float v[3] = {0.f, 0.f, 0.f};
                     if (rsh[u] >= 0) {
                         const unsigned long long q0 = rq0[u] >> (rpb[u] & 0xff), q1 = rq1[u] >> (rpb[u] >> 8);
-                        const int sh = rsh[u];
+                        const unsigned l0 = (unsigned)q0, h0 = (unsigned)(q0 >> 32), l1 = (unsigned)q1, h1 = (unsigned)(q1 >> 32);
+                        const bool two = rsh[u] != 0;                 // x1 = x0 + 1 (else the clamped border: x1 = x0)
+                        // bytes of a row piece: B0 G0 R0 B1 | G1 R1 . .   (v_cvt_f32_ubyteN each); output order R, G, B
+                        const float a00[3] = {(float)((l0 >> 16) & 0xff), (float)((l0 >> 8) & 0xff), (float)(l0 & 0xff)};
+                        const float a01[3] = {(float)((h0 >> 8) & 0xff), (float)(h0 & 0xff), (float)(l0 >> 24)};
+                        const float a10[3] = {(float)((l1 >> 16) & 0xff), (float)((l1 >> 8) & 0xff), (float)(l1 & 0xff)};
+                        const float a11[3] = {(float)((h1 >> 8) & 0xff), (float)(h1 & 0xff), (float)(l1 >> 24)};
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
-                            const int ci = 2 - c;                   // BGR -> RGB
-                            const float sv = dbilerp((float)(unsigned)((q0 >> (8 * ci)) & 0xff), (float)(unsigned)((q0 >> (8 * ci + sh)) & 0xff),
-                                                     (float)(unsigned)((q1 >> (8 * ci)) & 0xff), (float)(unsigned)((q1 >> (8 * ci + sh)) & 0xff),
-                                                     rwx[u], rwy[u]);
+                            const float sv = dbilerp(a00[c], two ? a01[c] : a00[c], a10[c], two ? a11[c] : a10[c], rwx[u], rwy[u]);
                             v[c] = (sv - 127.5f) * 0.0078125f;
                         }
                     }
