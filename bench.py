@@ -133,7 +133,7 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import warnings
-    from facerecognition_infrenceengine_amd import FaceAnalysis, GalleryMatcher
+    from facerecognition_infrenceengine_amd import FaceAnalysis, GalleryMatcher, _lib
     from facerecognition_infrenceengine_amd.distributed import ShardedGalleryMatcher, shard_rows
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -259,6 +259,23 @@ def main():
         if not same:
             raise SystemExit(f"rank {rank}: pipelined step {last} disagrees with its sequential re-run - results invalid")
 
+    # ---- per-stage times of one batch alone on one stream (outside the timed region; HIP events)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev[0].record()
+    sb, ss, sk, sc = app.det.detect_batch(batches[0])
+    ev[1].record()
+    crops0 = torch.empty((FRAMES * FACES_PER_FRAME, 112, 112, 8), dtype=torch.float16, device=device)
+    app.lib.fr_warp_affine_5pt_slots(_lib.ptr(batches[0]), FRAMES, H, W, _lib.ptr(sk.contiguous()), _lib.ptr(sc),
+                                     FACES_PER_FRAME, 112, _lib.ptr(crops0), _lib.stream_ptr())
+    emb0, nrm0 = app.rec.forward(crops0)
+    ev[2].record()
+    i0, s0 = sharded.match(nrm0)
+    gm.decide_device(i0, s0, 0.4)
+    ev[3].record()
+    torch.cuda.synchronize()
+    stage_ms = {"detect": round(ev[0].elapsed_time(ev[1]), 3), "align_embed": round(ev[1].elapsed_time(ev[2]), 3),
+                "match": round(ev[2].elapsed_time(ev[3]), 3)}
+
     # ---- instrumented pass (outside the timed region): HIP events around every conv launch
     app.rec.profile = []
     r = app.detect_embed_slots(batches[0])
@@ -304,6 +321,7 @@ def main():
                "p50_batch_latency_ms": round(float(np.percentile(batch_ms, 50)), 3),
                "p95_batch_latency_ms": round(float(np.percentile(batch_ms, 95)), 3),
                "p50_face_latency_ms": round(float(np.percentile(batch_ms, 50)) / max(faces / world / args.steps, 1), 4),
+               "stage_ms_alone": stage_ms,
                "self_check": "last pipelined step == sequential single-stream re-run (ids, decisions, counts)",
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
