@@ -58,8 +58,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // (4 = two blocks per CU).
 // LEAN: one halo buffer, one fragment set, <= 128 VGPRs -> TWO blocks per CU (16 waves): the fixed cost of a
 // block (first loads, epilogue: ~30 % of a 28x28 tile) and its barrier stalls are covered by the neighbour.
-// NA: 16-cout MFMA tiles per wave (4 = 64 couts; 2 = 32 couts: used by the lean variant so that the 13 pixel
-// tiles split 7/6 over two pixel groups instead of 4/3/3/3 over four - 93 % instead of 81 % balanced).
+// NA: 16-cout MFMA tiles per wave (4 = 64 couts).  (A 32-cout / 2-pixel-group split was tried for balance: it spilled at
+// 128 VGPRs and was replaced by SPLIT below.)
 template <int WN, int NPT, int XROWS, int NXBUF, int MINW, bool STAMPS, bool LEAN = false, int NA = 4>
 __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -449,10 +449,8 @@ int fr_conv_halo_try(const fr_conv_args* a, hipStream_t s) {
         // FR_HALO_LEAN bit 0: 28x28 layers, bit 1: 14x14 layers run as two lean blocks per CU (default 3 = both)
         static int lean = -1;
         if (lean < 0) { const char* e = getenv("FR_HALO_LEAN"); lean = e ? atoi(e) : 3; }
-        static int na2 = -1;        // FR_HALO_NA2=1: 32 couts per wave x 2 pixel groups (7/6 tiles: better balanced, but spills at 128 VGPRs; measured no gain)
-        if (na2 < 0) { const char* e = getenv("FR_HALO_NA2"); na2 = e ? atoi(e) : 0; }
-        if ((lean & 1) && a->H == 28) rc = na2 ? launch_halo<4, 13, 320, 1, 4, true, 2>(p, s) : launch_halo<2, 13, 320, 1, 4, true>(p, s);
-        else if ((lean & 2) && a->H == 14) rc = na2 ? launch_halo<4, 13, 256, 1, 4, true, 2>(p, s) : launch_halo<2, 13, 256, 1, 4, true>(p, s);
+        if ((lean & 1) && a->H == 28) rc = launch_halo<2, 13, 320, 1, 4, true>(p, s);
+        else if ((lean & 2) && a->H == 14) rc = launch_halo<2, 13, 256, 1, 4, true>(p, s);
         else rc = (a->Cout % 256 == 0) ? launch_halo<4, 13, 320, 2, 2>(p, s) : launch_halo<2, 13, 320, 2, 2>(p, s);
     }
     return rc == FR_OK ? 1 : rc;
