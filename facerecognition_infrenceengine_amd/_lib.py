@@ -44,6 +44,7 @@ SIGNATURES = {
     "fr_cosine_matrix_f32": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "fr_mean_rows_f32": (_I, [_P, _I, _I, _P, _P]),
     "fr_conv_nhwc_f16": (_I, [C.POINTER(ConvArgs), _P]),
+    "fr_conv_splitk_epilogue": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
     "fr_fc_reduce_l2norm": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
     "fr_warp_affine_5pt": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "fr_warp_affine_5pt_slots": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P]),

@@ -463,6 +463,52 @@ extern "C" int fr_conv_nhwc_f16(const fr_conv_args* a, fr_stream_t stream) {
     return FR_OK;
 }
 
+// ---- split-K tail of an ordinary conv (small batches: too few output tiles to fill 256 CUs, so K is cut into
+// splitk slices that run side by side): sum the f32 partials, then the same epilogue as the fused path
+__global__ void conv_splitk_epilogue(const float* __restrict__ partial, int splitk, int M, int Cout, int Ho, int Wo,
+                                     const float* __restrict__ bias, int bias_mode, const float* __restrict__ slope,
+                                     const half_t* __restrict__ res, half_t* __restrict__ y) {
+    const int q4 = Cout / 4;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)M * q4) return;
+    const int m = (int)(e / q4), co = (int)(e - (int64_t)m * q4) * 4;
+    float4v v = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < splitk; ++z) v += *reinterpret_cast<const float4v*>(partial + ((size_t)z * M + m) * Cout + co);
+    if (bias) {
+        int bsel = 0;
+        if (bias_mode == 1) {
+            const int r = m % (Ho * Wo), ho = r / Wo, wo = r - ho * Wo;
+            const int rc = ho == 0 ? 0 : (ho == Ho - 1 ? 2 : 1), cc = wo == 0 ? 0 : (wo == Wo - 1 ? 2 : 1);
+            bsel = (rc * 3 + cc) * Cout;
+        }
+        v += *reinterpret_cast<const float4v*>(bias + bsel + co);
+    }
+    if (slope) {
+        const float4v sv = *reinterpret_cast<const float4v*>(slope + co);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.f ? v[c] : v[c] * sv[c];
+    }
+    if (res) {
+        const half4 rv = *reinterpret_cast<const half4*>(res + (size_t)m * Cout + co);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] += (float)rv[c];
+    }
+    *reinterpret_cast<half4*>(y + (size_t)m * Cout + co) = half4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+}
+
+extern "C" int fr_conv_splitk_epilogue(const float* partial, int splitk, int M, int Cout, int Ho, int Wo,
+                                       const float* bias, int bias_mode, const float* slope, const void* residual,
+                                       void* y, fr_stream_t stream) {
+    FR_REQUIRE(partial && y && splitk >= 1 && M > 0 && Cout > 0 && Cout % 4 == 0 && Ho > 0 && Wo > 0,
+               "fr_conv_splitk_epilogue: bad argument");
+    FR_REQUIRE(bias_mode == 0 || (bias_mode == 1 && bias && Ho >= 2 && Wo >= 2), "fr_conv_splitk_epilogue: bad bias mode");
+    const int64_t n = (int64_t)M * (Cout / 4);
+    conv_splitk_epilogue<<<(unsigned)((n + 255) / 256), 256, 0, fr_stream(stream)>>>(
+        partial, splitk, M, Cout, Ho, Wo, bias, bias_mode, slope, (const half_t*)residual, (half_t*)y);
+    FR_CHECK_LAUNCH("conv_splitk_epilogue");
+    return FR_OK;
+}
+
 // ---- FC tail: reduce split-K partials + bias -> embedding; L2-normalise (one wave per face)
 __global__ void fc_reduce_l2norm(const float* __restrict__ partial, int splitk, int B, int dim,
                                  const float* __restrict__ bias, float* __restrict__ emb, float* __restrict__ normed) {

@@ -111,6 +111,11 @@ typedef struct {
     int bias_mode; int splitk;
 } fr_conv_args;
 int fr_conv_nhwc_f16(const fr_conv_args* args, fr_stream_t stream);
+/* Split-K tail of an ordinary conv (small batches): y = epi(sum_z partial[z]) with the epilogue of fr_conv_nhwc_f16
+ * (bias or 9-class border bias, PReLU, residual, one rounding to f16).  partial: f32 [splitk][M][Cout]. */
+int fr_conv_splitk_epilogue(const float* partial, int splitk, int M, int Cout, int Ho, int Wo,
+                            const float* bias, int bias_mode, const float* slope, const void* residual,
+                            void* y, fr_stream_t stream);
 /* FC tail: sum split-K partials + bias -> embedding f32 [B,dim]; then
  * normed_embedding = embedding / ||embedding|| (Face.normed_embedding, infrenceServer.py:532) */
 int fr_fc_reduce_l2norm(const float* partial, int splitk, int B, int dim, const float* bias,
