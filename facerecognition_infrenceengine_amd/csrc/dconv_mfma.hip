@@ -464,9 +464,15 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
                 const int n = img0 + g, oy = y0 + ty, ox = x0 + tx;
                 if (n < a.B && oy < a.Ho && ox < a.Wo) {
                     float* o = a.y + (((int64_t)n * a.Ho + oy) * a.Wo + ox) * NHEAD + kq * 4;
+                    if constexpr (NHEAD % 2 == 0) {          // 8-byte stores (a pixel's NHEAD floats are 8-byte aligned)
+                        typedef float float2v __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<float2v*>(o) = float2v{hd[t][0], hd[t][1]};
+                        if (kq * 4 + 2 < NHEAD) *reinterpret_cast<float2v*>(o + 2) = float2v{hd[t][2], hd[t][3]};
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (kq * 4 + r < NHEAD) o[r] = hd[t][r];
+                        for (int r = 0; r < 4; ++r)
+                            if (kq * 4 + r < NHEAD) o[r] = hd[t][r];
+                    }
                 }
             }
         } else {
