@@ -54,3 +54,25 @@ def test_invalid_arguments_return_error_not_crash():
         lib.fr_dconv_mfma_f32(99, one, one, one, None, one, 1, 8, 8, None, None, None, 0, 0, None)
     with pytest.raises(_lib.FrError, match="bad argument"):
         lib.fr_conv_splitk_epilogue(None, 2, 10, 64, 7, 7, None, 0, None, None, None, None)
+
+
+def test_device_code_has_no_packed_f32_ops(tmp_path):
+    """packed-f32 VALU results went stale beside another stream's conv kernels, silently.  The
+    library is built with the feature off; this disassembles every gfx950 code object in it and checks."""
+    import shutil
+    import subprocess
+    from facerecognition_infrenceengine_amd import _lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    so = shutil.copy(_lib.LIB_PATH, tmp_path / "libfrhip.so")
+    subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, capture_output=True)
+    cos = [f for f in os.listdir(tmp_path) if "amdgcn" in f]
+    assert cos, "no device code objects found in libfrhip.so"
+    n_mfma = 0
+    for f in cos:
+        asm = subprocess.run([objdump, "-d", str(tmp_path / f)], capture_output=True, text=True, check=True).stdout
+        bad = re.findall(r"v_pk_(?:mul|add|fma)_f32", asm)
+        assert not bad, f"{len(bad)} packed-f32 ops in {f}: build with NOPK (csrc/Makefile)"
+        n_mfma += len(re.findall(r"v_mfma_f32_16x16x32[_a-z0-9]*f16", asm))
+    assert n_mfma > 100                      # and it really is the library with the MFMA kernels in it
