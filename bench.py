@@ -33,6 +33,7 @@ FRAMES, H, W = 64, 1080, 1920
 GALLERY_ROWS = 10_000
 FACES_PER_FRAME = 4                    # O-Net cap (C2 keeps F = 4 -> 256 faces/batch)
 MFMA_PEAK_TFLOPS = 2500.0              # dense f16/bf16 (MI355X_MICROARCH.md)
+PMC_FILE = "profiles/r02_pmc_traffic.json"
 
 
 def synth_frames(n, h, w, seed, device):
@@ -47,12 +48,16 @@ def synth_frames(n, h, w, seed, device):
     return (img.permute(0, 2, 3, 1).clamp(0, 1) * 255).round().to(torch.uint8).contiguous()
 
 
-def cpu_baseline(n_frames, rows):
-    """CPU oracle on a bounded sample of the same workload (rank 0, N == 1 only)."""
+def cpu_baseline(n_frames, rows, threads=None):
+    """CPU oracle on a bounded sample of the same workload (rank 0, N == 1 only).  ``threads``: torch intra-op
+    threads for the run (None = the process default = all host cores)."""
     from facerecognition_infrenceengine_amd import weights
     from oracle import align as oalign, detect as odetect, match as omatch, nets as onets
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from make_golden import synth_frame
+    default_threads = torch.get_num_threads()
+    if threads:
+        torch.set_num_threads(threads)
     cores = torch.get_num_threads()
     p, r, o = weights.synth_mtcnn_states()
     st = weights.synth_iresnet_state("r100")
@@ -75,9 +80,49 @@ def cpu_baseline(n_frames, rows):
             omatch.decide_live(*omatch.linear_scan(q, gal))          # literal per-row Python loop
             faces += 1
     dt = time.perf_counter() - t0
-    return {"value": faces / dt, "unit": "faces/s", "cores": cores, "kind": "port",
-            "sample": f"{n_frames} synthetic 1080p frames, {faces} faces, r100 fp32 torch-CPU + literal "
+    torch.set_num_threads(default_threads)
+    return {"value": faces / dt, "unit": "faces/s", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "port",
+            "sample": f"{n_frames} synthetic {H}x{W} frames, {faces} faces, r100 fp32 torch-CPU + literal "
                       f"{rows}-row Python match loop, {dt:.1f} s"}
+
+
+def c1_latency(app, device, n=30):
+    """BASELINE config C1 on the GPU: ONE 640x480 frame (host uint8), one face slot, 100-row gallery, through the
+    reference-shaped calls `get(frame)` + match; p50 of n calls, ms.  Eager and with HIP-graph replay."""
+    from facerecognition_infrenceengine_amd import GalleryMatcher
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden import synth_frame
+    frame = synth_frame(480, 640, 7)
+    app1 = app.clone_with(cap_o=1)
+    g = torch.Generator(device=device).manual_seed(2)
+    gm1 = GalleryMatcher(device)
+    gm1.set_rows(range(100), torch.randn((100, 512), generator=g, device=device), normalise=True)
+    out = {}
+    for tag, graphs in (("get_match_p50", False), ("get_match_graph_p50", True)):
+        app1.enable_graphs(graphs)
+        ts = []
+        for i in range(n + 5):
+            t0 = time.perf_counter()
+            faces = app1.get(frame)
+            if faces:
+                gm1.match(np.stack([f.normed_embedding for f in faces]))
+            ts.append((time.perf_counter() - t0) * 1e3)
+        out[tag] = round(float(np.percentile(ts[5:], 50)), 3)
+        out["faces"] = len(faces)
+    app1.enable_graphs(False)
+    return out
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) with torch.distributed.run as a
+    CHILD process - this process has not touched the GPU (importing torch does not) - pass rank 0's JSON line
+    through on stdout and exit with the launcher's code (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd).returncode)
 
 
 def main():
@@ -87,13 +132,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
+    ap.add_argument("--cpu-frames-1t", type=int, default=1, help="frames of the 1-thread CPU baseline (0 = skip)")
+    ap.add_argument("--no-side", action="store_true", help="skip the side measurements (value_pcie, latency_c1_ms)")
     ap.add_argument("--depth", type=int, default=3, help="steps in flight before the oldest one's ids are fetched")
     ap.add_argument("--ingest", default="resident", choices=["resident", "pinned"],
                     help="resident: frames already in HBM (the headline metric); pinned: every step's frames cross "
                          "PCIe from a pinned host ring on a copy stream (reported in DESIGN.md, never the headline)")
     ap.add_argument("--gallery-rows", type=int, default=0, help="override the gallery size (C4: 1 000 000 rows in total)")
-    ap.add_argument("--gallery", default="f32", choices=["f32", "f16"],
-                    help="f16: coarse scan of an f16 copy on the f16 matrix cores + exact f32 re-rank of the top 4")
+    ap.add_argument("--gallery", default="f32", choices=["f32", "f16", "f8"],
+                    help="f16 / f8: one-pass coarse scan of a 16- / 8-bit copy on the f16 / fp8 matrix cores + exact f32 "
+                         "re-rank of the top 4 / 8")
     ap.add_argument("--force-exchange", action="store_true",
                     help="with one rank: still run the two all-gathers of the sharded match over RCCL (rehearsal)")
     ap.add_argument("--pipes", type=int, default=2, help="independent (detector, embedder) stream pairs, used round-robin")
@@ -116,8 +164,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -134,7 +182,7 @@ def main():
 
     import warnings
     from facerecognition_infrenceengine_amd import FaceAnalysis, GalleryMatcher, _lib
-    from facerecognition_infrenceengine_amd.distributed import ShardedGalleryMatcher, shard_rows
+    from facerecognition_infrenceengine_amd.distributed import HipOps, ShardedGalleryMatcher, shard_rows
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         app = FaceAnalysis(name="synthetic", arch="r100", cap_o=FACES_PER_FRAME)
@@ -144,11 +192,10 @@ def main():
     g = torch.Generator(device=device).manual_seed(1)
     G = torch.randn((GALLERY_ROWS, 512), generator=g, device=device)
     lo, hi = shard_rows(GALLERY_ROWS, world, rank)
-    gm = GalleryMatcher(device, f16_scan=args.gallery == "f16")
+    gm = GalleryMatcher(device, scan=args.gallery)
     gm.set_rows(range(lo, hi), G[lo:hi].contiguous(), normalise=True)
     q_max = FRAMES * FACES_PER_FRAME
-    sharded = ShardedGalleryMatcher(lambda Q: gm.match_device(Q, renormalise=True, row_offset=lo), q_max,
-                                    force_exchange=args.force_exchange)
+    sharded = ShardedGalleryMatcher(HipOps(gm, lo), q_max, force_exchange=args.force_exchange)
 
     nbatch = min(max(args.steps, 1), 3)
     batches = [synth_frames(FRAMES, H, W, rank * 1000 + i, device) for i in range(nbatch)]
@@ -175,69 +222,75 @@ def main():
                "dec": torch.empty(q_rows, dtype=torch.int32).pin_memory(),
                "counts": torch.empty(FRAMES, dtype=torch.int32).pin_memory()} for _ in range(args.depth)]
 
-    def enqueue(i):
-        """One step, enqueued without any host synchronisation: fixed per-frame face slots, device-side counts,
-        asynchronous copy of the ids / decisions / counts to pinned host memory."""
-        t_in = time.perf_counter()
-        host = pinned[i % args.depth]
-        s_det, s_emb = pipes[i % len(pipes)]
-        with torch.cuda.stream(s_emb):
-            if ingest is not None:          # PCIe-inclusive variant: pinned host ring -> device on a copy stream
-                frames, ready = ingest.upload(i)
-                r = app.detect_embed_slots(frames, det_stream=s_det, ready_event=ready)
-                ingest.release(i)           # the warp (last reader of the frames) is queued on this stream by now
-            else:
-                r = app.detect_embed_slots(batches[i % nbatch], det_stream=s_det)
-            idx, score = sharded.match(r["normed_embedding"])
-            dec = gm.decide_device(idx, score, 0.4)
-            host["idx"].copy_(idx.to(torch.int64), non_blocking=True)
-            host["dec"].copy_(dec.to(torch.int32), non_blocking=True)
-            host["counts"].copy_(r["counts"], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(s_emb)
-        return host, ev, (idx, dec, r, s_emb), t_in
+    def run_loop(ingest, steps, warmup):
+        """warmup untimed steps, then `steps` timed steps bracketed by barrier + synchronize on both sides.
+        Returns (seconds, faces, batch latencies ms, per-step (idx, dec, counts) host copies)."""
+        batch_ms, results = [], []
 
-    def fetch(pending):
-        """ids on the host = end of the step; faces = detected faces (slots beyond a frame's count are ignored)."""
-        host, ev, _keep, t_in = pending
-        ev.synchronize()
-        batch_ms.append((time.perf_counter() - t_in) * 1e3)      # frames handed over -> ids on the host
-        results.append((host["idx"].clone(), host["dec"].clone(), host["counts"].clone()))   # 3 KB, for the self-check
-        return int(host["counts"].sum())
+        def enqueue(i):
+            """One step, enqueued without any host synchronisation: fixed per-frame face slots, device-side counts,
+            asynchronous copy of the ids / decisions / counts to pinned host memory."""
+            t_in = time.perf_counter()
+            host = pinned[i % args.depth]
+            s_det, s_emb = pipes[i % len(pipes)]
+            with torch.cuda.stream(s_emb):
+                if ingest is not None:          # PCIe-inclusive variant: pinned host ring -> device on a copy stream
+                    frames, ready = ingest.upload(i)
+                    r = app.detect_embed_slots(frames, det_stream=s_det, ready_event=ready)
+                    ingest.release(i)           # the warp (last reader of the frames) is queued on this stream by now
+                else:
+                    r = app.detect_embed_slots(batches[i % nbatch], det_stream=s_det)
+                idx, score = sharded.match(r["normed_embedding"])
+                dec = gm.decide_device(idx, score, 0.4)
+                host["idx"].copy_(idx.to(torch.int64), non_blocking=True)
+                host["dec"].copy_(dec.to(torch.int32), non_blocking=True)
+                host["counts"].copy_(r["counts"], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(s_emb)
+            return host, ev, (idx, dec, r, s_emb), t_in
+
+        def fetch(pending):
+            """ids on the host = end of the step; faces = detected faces (slots beyond a frame's count are ignored)."""
+            host, ev, _keep, t_in = pending
+            ev.synchronize()
+            batch_ms.append((time.perf_counter() - t_in) * 1e3)      # frames handed over -> ids on the host
+            results.append((host["idx"].clone(), host["dec"].clone(), host["counts"].clone()))   # 3 KB, for the self-check
+            return int(host["counts"].sum())
+
+        def step(i, pending):
+            """Software pipeline of depth args.depth: step i is enqueued before step i-depth+1's ids are pulled to the
+            host, so neither HIP stream waits for the Python driver between steps."""
+            pending.append(enqueue(i))
+            return fetch(pending.popleft()) if len(pending) >= args.depth else 0
+
+        def drain(pending):
+            n = 0
+            while pending:
+                n += fetch(pending.popleft())
+            return n
+
+        pending = deque()
+        for i in range(warmup):
+            step(i, pending)
+        drain(pending)
+        sync()
+        t0 = time.perf_counter()
+        faces = 0
+        batch_ms.clear(); results.clear()
+        for i in range(steps):
+            faces += step(i, pending)
+        faces += drain(pending)                    # all K steps' ids are on the host inside the timed region
+        sync()
+        return time.perf_counter() - t0, faces, batch_ms, results
 
     from collections import deque
-
-    def step(i, pending):
-        """Software pipeline of depth args.depth: step i is enqueued before step i-depth+1's ids are pulled to the
-        host, so neither HIP stream waits for the Python driver between steps."""
-        pending.append(enqueue(i))
-        return fetch(pending.popleft()) if len(pending) >= args.depth else 0
-
-    def drain(pending):
-        n = 0
-        while pending:
-            n += fetch(pending.popleft())
-        return n
 
     def sync():
         if world > 1 or args.force_exchange:
             dist.barrier()
         torch.cuda.synchronize()
 
-    batch_ms, results = [], []
-    pending = deque()
-    for i in range(args.warmup):
-        step(i, pending)
-    drain(pending)
-    sync()
-    t0 = time.perf_counter()
-    faces = 0
-    batch_ms.clear(); results.clear()
-    for i in range(args.steps):
-        faces += step(i, pending)
-    faces += drain(pending)                    # all K steps' ids are on the host inside the timed region
-    sync()
-    dt = time.perf_counter() - t0
+    dt, faces, batch_ms, results = run_loop(ingest, args.steps, args.warmup)
     tot = torch.tensor([dt, float(faces)], dtype=torch.float64, device=device)
     if world > 1:
         tmax = tot.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -247,6 +300,7 @@ def main():
     # ---- self-check (outside the timed region): EVERY timed step's ids / decisions / counts must equal a sequential
     # single-stream run of the batch that step processed (cross-stream hazards are silent: DESIGN.md 4.7)
     expect = {}
+    bad_step = -1
     for k, (idx_h, dec_h, cnt_h) in enumerate(results):
         src = (k % ingest.depth) % nbatch if ingest is not None else k % nbatch      # the batch step k used
         if src not in expect:
@@ -257,7 +311,18 @@ def main():
         idx2, dec2, cnt2 = expect[src]
         valid = (torch.arange(FACES_PER_FRAME)[None, :] < cnt2[:, None]).reshape(-1)      # empty slots are undefined
         if not (torch.equal(cnt2, cnt_h) and torch.equal(idx2[valid], idx_h[valid]) and torch.equal(dec2[valid], dec_h[valid])):
-            raise SystemExit(f"rank {rank}: pipelined step {k} disagrees with its sequential re-run - results invalid")
+            bad_step = k if bad_step < 0 else bad_step      # no break: sharded.match above is a collective
+    # the verdict is collective: a rank that left alone would strand its peers in the next barrier
+    flag = torch.tensor([1.0 if bad_step >= 0 else 0.0], device=device)
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if float(flag[0]) > 0:
+        if bad_step >= 0:
+            print(f"rank {rank}: pipelined step {bad_step} disagrees with its sequential re-run - results invalid",
+                  file=sys.stderr, flush=True)
+        if world > 1 or args.force_exchange:
+            dist.destroy_process_group()
+        sys.exit(3)
 
     # ---- per-stage times of one batch alone on one stream (outside the timed region; HIP events)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -292,7 +357,7 @@ def main():
     # note inside the file for the gfx950 FETCH_SIZE correction); None when no record matches the kernel
     traffic = None
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        rec = json.load(open(os.path.join(ROOT, PMC_FILE)))["kernels"]
         hits = [v for k, v in rec.items() if k.startswith(dom + " ") and "hbm_bytes_per_launch_corrected" in v]
         if hits:            # the kernel serves several layer shapes: take the one with the most launches
             traffic = max(hits, key=lambda v: v.get("dispatches", 0))["hbm_bytes_per_launch_corrected"]
@@ -300,8 +365,25 @@ def main():
         pass
     roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_source": f"{PMC_FILE}: rocprofv3 --pmc passes of tools/pmc_traffic.py (separate run; counters "
+                                  "cannot be read from inside this process)" if traffic is not None else None,
                 "launches_per_step": calls, "avg_launch_us": round(secs / calls * 1e6, 2),
                 "algorithmic_gflop_per_launch": round(flops / calls / 1e9, 3)}
+
+    # ---- side measurements for the other half of BASELINE's metric (rank 0, one GPU, default workload only)
+    side = {}
+    if world == 1 and args.workload == "C2" and not args.no_side:
+        if args.ingest == "resident":           # PCIe-inclusive rate: every step's 398 MB cross PCIe from a pinned ring
+            from facerecognition_infrenceengine_amd.ingest import FrameIngest
+            ing = FrameIngest(FRAMES, H, W, device, depth=args.depth + 1)
+            for k in range(ing.depth):
+                ing.host_buffer(k)[...] = batches[k % nbatch].cpu().numpy()
+            n_p = max(6, min(args.steps, 12))
+            dt_p, faces_p, _, _ = run_loop(ing, n_p, 2)
+            side["value_pcie"] = round(faces_p / dt_p, 1)
+            side["value_pcie_note"] = f"{n_p} steps, frames uploaded from pinned host memory on a copy stream every step"
+            del ing
+        side["latency_c1_ms"] = c1_latency(app, device)
 
     if rank == 0:
         out = {"metric": "faces/sec end-to-end @1080p" if args.workload == "C2" else f"faces/sec end-to-end @{H}p", "value": round(faces / dt, 1), "unit": "faces/s",
@@ -321,11 +403,13 @@ def main():
                "p50_batch_latency_ms": round(float(np.percentile(batch_ms, 50)), 3),
                "p95_batch_latency_ms": round(float(np.percentile(batch_ms, 95)), 3),
                "p50_face_latency_ms": round(float(np.percentile(batch_ms, 50)) / max(faces / world / args.steps, 1), 4),
-               "stage_ms_alone": stage_ms,
+               "stage_ms_alone": stage_ms, **side,
                "self_check": f"all {len(results)} timed steps == sequential single-stream re-run (ids, decisions, counts)",
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_frames, GALLERY_ROWS)
+            if args.cpu_frames_1t:              # the same port on ONE thread, beside the all-core figure
+                out["cpu_baseline_1thread"] = cpu_baseline(args.cpu_frames_1t, GALLERY_ROWS, threads=1)
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_exchange:
         dist.barrier()

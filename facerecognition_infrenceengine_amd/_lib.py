@@ -33,13 +33,18 @@ SIGNATURES = {
     "fr_device_count": (_I, []),
     "fr_l2norm_rows_f32": (_I, [_P, _P, _I, _I, _P]),
     "fr_gallery_match_workspace": (_Z, [_I, _L]),
-    "fr_gallery_match_f32": (_I, [_P, _P, _I, _L, _I, _L, _P, _P, _P, _Z, _P]),
+    "fr_gallery_match_f32": (_I, [_P, _P, _I, _L, _I, _L, _P, _P, _P, _Z, _P, _I, _P]),
     "fr_gallery_match_view_f32": (_I, [_P, _P, _P, _I, _L, _I, _P, _P, _P, _Z, _P]),
     "fr_gallery_update_rows_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "fr_gallery_match_f16_workspace": (_Z, [_I, _L]),
-    "fr_gallery_match_f16": (_I, [_P, _P, _P, _I, _L, _I, _L, _P, _P, _P, _Z, _P]),
+    "fr_gallery_match_f16": (_I, [_P, _P, _P, _I, _L, _I, _L, _P, _P, _P, _Z, _P, _I, _P]),
+    "fr_gallery_match_f8_workspace": (_Z, [_I, _L]),
+    "fr_gallery_match_f8": (_I, [_P, _P, _P, _I, _L, _I, _L, _P, _P, _P, _Z, _P, _I, _P]),
+    "fr_f32_to_f8": (_I, [_P, _P, _L, _P]),
     "fr_f32_to_f16": (_I, [_P, _P, _L, _P]),
     "fr_match_decide": (_I, [_P, _P, _I, _F, _F, _P, _P]),
+    "fr_match_pack_candidates": (_I, [_P, _P, _I, _P, _P]),
+    "fr_match_reduce_shards": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "fr_gallery_first_above_f32": (_I, [_P, _P, _I, _L, _I, _F, _I, _L, _P, _P, _P, _Z, _P]),
     "fr_cosine_matrix_f32": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "fr_mean_rows_f32": (_I, [_P, _I, _I, _P, _P]),
@@ -92,6 +97,16 @@ class Lib:
             return self.__dict__["_calls"][name]
         except KeyError:
             raise AttributeError(name)
+
+
+def use_library(path):
+    """Developer tools only (tools/stamp_*.py): bind the diagnostic twin ``libfrhip_debug.so`` (``make debug``)
+    instead of the product library.  Must be called before the first ``load()``."""
+    global LIB_PATH, _lib
+    with _lock:
+        if _lib is not None:
+            raise FrError("use_library() must be called before the library is loaded")
+        LIB_PATH = path
 
 
 def load():

@@ -16,7 +16,6 @@
 // offset only) -> 2 x (A and B fragments via ds_read_b128, 13 MFMAs); at a chunk end: barrier + halo reload.
 // No gather arithmetic in the loop: per-lane halo bases are fixed, taps are scalar row offsets.
 #include "common.h"
-#include <cstdlib>
 #include <type_traits>
 
 struct HaloP {
@@ -406,18 +405,22 @@ static int launch_halo(const HaloP& p, hipStream_t s) {
     constexpr size_t opnd = (size_t)(NXBUF * XROWS * HK + 2 * BN * HK) * sizeof(half_t);
     constexpr size_t epi = (size_t)NPT * 16 * (BN + 8) * sizeof(half_t);          // output staging tile
     constexpr size_t lds = opnd > epi ? opnd : epi;
-    auto kern = p.stamps ? conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, true, LEAN, NA>
-                         : conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, false, LEAN, NA>;
-    static bool done[2] = {false, false};
-    if (!done[p.stamps ? 1 : 0]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) {
-            fr_set_error("conv_halo: cannot raise dynamic LDS to %zu bytes", lds);
-            return FR_E_LAUNCH;
-        }
-        done[p.stamps ? 1 : 0] = true;
-    }
     const int blocks = p.B * p.tiles_per_img * (p.Cout / BN);
+    if constexpr (FR_DEBUG) {                  // stamped twin: debug build only
+        if (p.stamps) {
+            static FrDevLatch dl;
+            auto dk = conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, true, LEAN, NA>;
+            if (!fr_raise_lds(reinterpret_cast<const void*>(dk), lds, dl)) { fr_set_error("conv_halo: cannot raise dynamic LDS"); return FR_E_LAUNCH; }
+            dk<<<blocks, 512, lds, s>>>(p);
+            return FR_OK;
+        }
+    }
+    static FrDevLatch latch;
+    auto kern = conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, false, LEAN, NA>;
+    if (!fr_raise_lds(reinterpret_cast<const void*>(kern), lds, latch)) {
+        fr_set_error("conv_halo: cannot raise dynamic LDS to %zu bytes", lds);
+        return FR_E_LAUNCH;
+    }
     kern<<<blocks, 512, lds, s>>>(p);
     return FR_OK;
 }
@@ -441,17 +444,18 @@ int fr_conv_halo_try(const fr_conv_args* a, hipStream_t s) {
     p.TH = TH; p.tiles_per_img = a->H / TH;
     p.xbytes = (unsigned)((int64_t)a->B * a->H * a->W * a->Cin * 2);
     p.wbytes = (unsigned)((int64_t)a->Cout * 9 * a->Cin * 2);
-    { static long long sp = -1; if (sp < 0) { const char* e = getenv("FR_DBG_STAMPS"); sp = e ? strtoll(e, nullptr, 0) : 0; } p.stamps = (unsigned long long*)sp; }
+    p.stamps = (unsigned long long*)fr_dbg_ptr("FR_DBG_STAMPS");        // always NULL in the product build
     int rc;
     if (a->H == 56) rc = launch_halo<1, 14, 384, 1, 4>(p, s);
     else if (a->H == 112) rc = launch_halo<1, 14, 512, 1, 4>(p, s);
     else {
-        // FR_HALO_LEAN bit 0: 28x28 layers, bit 1: 14x14 layers run as two lean blocks per CU (default 3 = both)
-        static int lean = -1;
-        if (lean < 0) { const char* e = getenv("FR_HALO_LEAN"); lean = e ? atoi(e) : 3; }
+        // 28x28 and 14x14 layers run as two lean blocks per CU.  Debug build: FR_HALO_LEAN bit 0 / bit 1 = 0 selects
+        // the pipelined one-block-per-CU schedule for 28x28 / 14x14 instead (kept as a measured alternative).
+        const int lean = fr_dbg_int("FR_HALO_LEAN", 3);
         if ((lean & 1) && a->H == 28) rc = launch_halo<2, 13, 320, 1, 4, true>(p, s);
         else if ((lean & 2) && a->H == 14) rc = launch_halo<2, 13, 256, 1, 4, true>(p, s);
-        else rc = (a->Cout % 256 == 0) ? launch_halo<4, 13, 320, 2, 2>(p, s) : launch_halo<2, 13, 320, 2, 2>(p, s);
+        else if constexpr (FR_DEBUG) rc = (a->Cout % 256 == 0) ? launch_halo<4, 13, 320, 2, 2>(p, s) : launch_halo<2, 13, 320, 2, 2>(p, s);
+        else rc = FR_E_INVALID;
     }
     return rc == FR_OK ? 1 : rc;
 }

@@ -15,7 +15,6 @@
 //   ds_read_b128 fragment reads of the 16x16x32 operand layout.
 // Zero padding / M tail: buffer loads with the offset forced out of range return 0.
 #include "common.h"
-#include <cstdlib>
 
 #define BK 64
 
@@ -253,7 +252,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pipelined variant (the product path): K step 32, ring of 4 LDS stages (16 KB each, 64 KB/block,
+// Four-stage ring variant (NOT on the product path: measured slower than the two-stage kernel above, compiled into
+// the debug build only, FR_CONV_KERNEL=2): K step 32, ring of 4 LDS stages (16 KB each, 64 KB/block,
 // 2 blocks/CU), tiles staged by LDS-DMA (buffer_load ... lds) that stay in flight ACROSS barriers:
 // per step  s_waitcnt vmcnt(8) [stage s landed; s+1, s+2 may still fly] -> raw s_barrier ->
 // issue stage s+3 into the buffer freed by step s-1 -> 8 ds_read_b128 + 16 MFMA on stage s.
@@ -385,33 +385,29 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pipe(ConvP p) {
 // Generic-path variant (layers the halo kernel does not take): FR_CONV_KERNEL = 1 (default) two-stage
 // LDS-DMA loader, K step 64; 2 = four-stage LDS-DMA ring, K step 32 (slower: a barrier per 16 MFMAs and ~100
 // cycles of issue per LDS-DMA piece outweigh the deeper prefetch); 0 = two-stage register-staged loader.
-static int conv_kernel_choice() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("FR_CONV_KERNEL"); v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }
-    return v;
-}
+static int conv_kernel_choice() { return fr_dbg_int("FR_CONV_KERNEL", 1); }      // product build: always 1
 
 template <int WN, bool SMALL>
 static void launch_conv(const ConvP& p, hipStream_t s) {
     constexpr int BN = 64 * WN, BM = 64 * (4 / WN);
     dim3 grid((p.M + BM - 1) / BM, p.Cout / BN, p.splitk > 1 ? p.splitk : 1);
-    const int which = conv_kernel_choice();
-    if (which == 2) {
-        ConvP q = p;
-        q.nk = p.K / PK;
-        dim3 g1(grid.x * grid.y, 1, grid.z);
-        conv_mfma_pipe<WN, SMALL><<<g1, 256, 0, s>>>(q);
-    } else if (which == 1) conv_mfma_kernel<WN, SMALL, true><<<grid, 256, 0, s>>>(p);
-    else conv_mfma_kernel<WN, SMALL, false><<<grid, 256, 0, s>>>(p);
+    if constexpr (FR_DEBUG) {                  // measured alternatives, debug build only
+        const int which = conv_kernel_choice();
+        if (which == 2) {
+            ConvP q = p;
+            q.nk = p.K / PK;
+            dim3 g1(grid.x * grid.y, 1, grid.z);
+            conv_mfma_pipe<WN, SMALL><<<g1, 256, 0, s>>>(q);
+            return;
+        }
+        if (which == 0) { conv_mfma_kernel<WN, SMALL, false><<<grid, 256, 0, s>>>(p); return; }
+    }
+    conv_mfma_kernel<WN, SMALL, true><<<grid, 256, 0, s>>>(p);
 }
 
 int fr_conv_halo_try(const fr_conv_args* a, hipStream_t s);     // conv_halo.hip
 
-static bool conv_halo_enabled() {                             // FR_CONV_HALO=0 disables the halo kernel (A/B)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("FR_CONV_HALO"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v == 1;
-}
+static bool conv_halo_enabled() { return fr_dbg_int("FR_CONV_HALO", 1) != 0; }   // debug build: FR_CONV_HALO=0 for A/B
 
 extern "C" int fr_conv_nhwc_f16(const fr_conv_args* a, fr_stream_t stream) {
     FR_REQUIRE(a, "fr_conv_nhwc_f16: null args");

@@ -16,7 +16,6 @@
 // Optional fused epilogues: PReLU, 2x2/s2 ceil-mode max pool (P-Net conv1), 1x1 head (P-Net
 // conv3 -> 2 logits + 4 regressions).
 #include "common.h"
-#include <cstdlib>
 
 struct DcArgs {
     const float* x; const float* w; const float* bias; const float* slope; float* y;
@@ -30,7 +29,7 @@ struct DcArgs {
 
 #define DSTAMP(var)                                                                               \
     do {                                                                                          \
-        if (a.stamps) {                                                                           \
+        if (FR_DEBUG && a.stamps) {                                                                        \
             __builtin_amdgcn_sched_barrier(0);                                                    \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");            \
             __builtin_amdgcn_sched_barrier(0);                                                    \
@@ -282,7 +281,7 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
         const int item = item0 + rr;
         if (item >= nitems) break;
         DSTAMP(d0);
-        if (a.stamps && rr == 0) q01 += d0 - dk;          // block prologue (first tile load, weights) counted once
+        if (FR_DEBUG && a.stamps && rr == 0) q01 += d0 - dk;          // block prologue (first tile load, weights) counted once
         const int zz = item / per_img, rem = item - zz * per_img;
         const int ry = rem / a.regions_x, rx = rem - ry * a.regions_x;
         const int y0 = ry * RSY, x0 = rx * RSX, img0 = zz * G;
@@ -504,9 +503,9 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
             store_tile();
         }
         DSTAMP(d4);
-        if (a.stamps) { q01 += d1 - d0; q12 += d2 - d1; q23 += d3 - d2; q34 += d4 - d3; }
+        if (FR_DEBUG && a.stamps) { q01 += d1 - d0; q12 += d2 - d1; q23 += d3 - d2; q34 += d4 - d3; }
     }
-    if (a.stamps && lane == 0) {
+    if (FR_DEBUG && a.stamps && lane == 0) {
         unsigned long long* o = a.stamps + ((size_t)(blockIdx.x % 4096) * NW + wave) * 4;
         o[0] = q01; o[1] = q12; o[2] = q23; o[3] = q34;
     }
@@ -534,14 +533,10 @@ static int launch_dc(const DcArgs& a0, hipStream_t s) {
     const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
     auto kern = dconv_mfma<CIN, COUT, KH, KW, RH, RW, G, NTB, WN, TG, POOL, PK, RSY, RSX, NHEAD, RPB, SRC, NW>;
     if (lds > 64 * 1024) {
-        static bool done = false;       // attribute is per function; benign race (idempotent)
-        if (!done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds) != hipSuccess) {
-                fr_set_error("fr_dconv_mfma_f32: cannot raise dynamic LDS to %zu bytes", lds);
-                return FR_E_LAUNCH;
-            }
-            done = true;
+        static FrDevLatch latch;        // per (kernel instantiation, device)
+        if (!fr_raise_lds(reinterpret_cast<const void*>(kern), lds, latch)) {
+            fr_set_error("fr_dconv_mfma_f32: cannot raise dynamic LDS to %zu bytes", lds);
+            return FR_E_LAUNCH;
         }
     }
     kern<<<grid, NW * 64, lds, s>>>(a);
@@ -554,15 +549,14 @@ extern "C" int fr_dconv_mfma_f32(int layer, const float* x, const float* w, cons
                                  const uint8_t* frames, int FH, int FW, fr_stream_t stream) {
     FR_REQUIRE(w && bias && y && B > 0 && H > 0 && W > 0, "fr_dconv_mfma_f32: bad argument");
     FR_REQUIRE((layer == 0) ? (frames && FH > 0 && FW > 0) : (x != nullptr), "fr_dconv_mfma_f32: no input");
-    static long long sp = -1;
-    if (sp < 0) { const char* e = getenv("FR_DBG_STAMPS"); sp = e ? strtoll(e, nullptr, 0) : 0; }
-    DcArgs a{x, w, bias, slope, y, head_w, head_b, B, H, W, 0, 0, 0, 0, frames, FH, FW, (unsigned long long*)sp};
+    DcArgs a{x, w, bias, slope, y, head_w, head_b, B, H, W, 0, 0, 0, 0, frames, FH, FW,
+             (unsigned long long*)fr_dbg_ptr("FR_DBG_STAMPS")};          // NULL in the product build
     hipStream_t s = fr_stream(stream);
     int rc = FR_OK;
     switch (layer) {
         //                  CIN COUT KH KW RH  RW  G NTB WN TG POOL PK RSY RSX NHEAD RPB SRC
         case 0:  FR_REQUIRE(H >= 3 && W >= 3 && frames, "P1 needs frames and a level of at least 3x3");
-                 { static int v = -1; if (v < 0) { const char* e = getenv("FR_P1_RPB"); v = e ? atoi(e) : 8; }
+                 { const int v = fr_dbg_int("FR_P1_RPB", 8);
                  const bool big = (int64_t)((H - 2 + 15) / 16) * ((W - 2 + 31) / 32) * B >= 8192;
                  if (big && v == 2) rc = launch_dc<3, 12, 3, 3, 16, 32, 1, 1, 1, 9, 1, 2, 16, 32, 0, 2, 1>(a, s);
                  else if (big && v == 4) rc = launch_dc<3, 12, 3, 3, 16, 32, 1, 1, 1, 9, 1, 2, 16, 32, 0, 4, 1>(a, s);
@@ -577,7 +571,7 @@ extern "C" int fr_dconv_mfma_f32(int layer, const float* x, const float* w, cons
                      rc = launch_dc<12, 16, 3, 3, 8, 32, 1, 1, 1, 9, 0, 2, 8, 32, 0, 8, 0>(a, s);
                  break;                                                                                   // P-Net conv2
         case 2:  FR_REQUIRE(H >= 3 && W >= 3 && head_w && head_b, "P3 needs head weights");
-                 { static int v = -1; if (v < 0) { const char* e = getenv("FR_P3_RPB"); v = e ? atoi(e) : 8; }
+                 { const int v = fr_dbg_int("FR_P3_RPB", 8);
                  if (v == 1 || (int64_t)((H - 2 + 7) / 8) * ((W - 2 + 31) / 32) * B < 8192)
                      rc = launch_dc<16, 32, 3, 3, 8, 32, 1, 2, 1, 9, 0, 2, 8, 32, 6, 1, 0>(a, s);
                  else if (v == 2)

@@ -17,6 +17,20 @@
 
 struct BestPair { float s; int64_t i; };
 
+// query slot q belongs to segment q / seg_len and is real iff its position in the segment < seg_counts[segment]
+__device__ __forceinline__ bool slot_valid(const int32_t* seg_counts, int seg_len, int q) {
+    const int seg = q / seg_len;
+    return q - seg * seg_len < seg_counts[seg];
+}
+__device__ __forceinline__ bool group_has_valid(const int32_t* seg_counts, int seg_len, int qa, int qb) {
+    // [qa, qb) spans at most a few segments; a segment contributes iff its first slot inside the range is real
+    for (int q = qa; q < qb;) {
+        if (slot_valid(seg_counts, seg_len, q)) return true;
+        q = (q / seg_len + 1) * seg_len;
+    }
+    return false;
+}
+
 __device__ __forceinline__ void take_better(float& bs, int64_t& bi, float s, int64_t i) {
     // max score; lowest index on exact ties (== first maximum in row order)
     if (s > bs || (s == bs && i < bi && i >= 0)) { bs = s; bi = i; }
@@ -28,10 +42,14 @@ template <bool VIEW>
 __global__ __launch_bounds__(256) void gallery_scan_f32(const float* __restrict__ Q, const float* __restrict__ G,
                                                         const int64_t* __restrict__ view,
                                                         int F, int64_t N, float* __restrict__ ws_score,
-                                                        int64_t* __restrict__ ws_idx) {
+                                                        int64_t* __restrict__ ws_idx,
+                                                        const int32_t* __restrict__ seg_counts, int seg_len) {
     __shared__ __attribute__((aligned(16))) float qs[QG * QPAD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q0 = blockIdx.y * QG;
+    // query slots beyond their segment's count are padding (sharded match: SURVEY.md 8(e)); a group made of
+    // padding only does no work (the reduce reports (-1, -1) for every padding slot)
+    if (seg_counts && !group_has_valid(seg_counts, seg_len, q0, min(q0 + QG, F))) return;
     // stage the query group (zero rows beyond F)
     for (int e = tid; e < QG * (GD / 4); e += 256) {
         int r = e / (GD / 4), c = e % (GD / 4);
@@ -92,9 +110,10 @@ __global__ __launch_bounds__(256) void gallery_scan_f32(const float* __restrict_
 
 __global__ void gallery_reduce(const float* __restrict__ ws_score, const int64_t* __restrict__ ws_idx, int nblk,
                                int F, int64_t row_offset, int64_t* __restrict__ out_idx,
-                               float* __restrict__ out_score) {
+                               float* __restrict__ out_score, const int32_t* __restrict__ seg_counts, int seg_len) {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
+    if (seg_counts && !slot_valid(seg_counts, seg_len, f)) { out_idx[f] = -1; out_score[f] = -1.0f; return; }
     float bs = -INFINITY; int64_t bi = -1;
     for (int b = 0; b < nblk; ++b) {
         int64_t i = ws_idx[(int64_t)b * F + f];
@@ -120,7 +139,8 @@ extern "C" size_t fr_gallery_match_workspace(int F, int64_t N) {
 
 static int gallery_match_launch(const char* who, const float* Q, const float* G, const int64_t* view, int F, int64_t N,
                                 int D, int64_t row_offset, int64_t* out_idx, float* out_score, void* workspace,
-                                size_t workspace_bytes, fr_stream_t stream) {
+                                size_t workspace_bytes, const int32_t* seg_counts, int seg_len, fr_stream_t stream) {
+    FR_REQUIRE(!seg_counts || (seg_len > 0 && F % seg_len == 0), "%s: seg_len must divide F", who);
     FR_REQUIRE(D == GD, "%s: D must be %d (got %d)", who, GD, D);
     FR_REQUIRE(F >= 0 && N >= 0, "%s: negative size", who);
     if (F == 0) return FR_OK;
@@ -133,19 +153,19 @@ static int gallery_match_launch(const char* who, const float* Q, const float* G,
     int64_t* ws_idx = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(workspace) + off);
     hipStream_t s = fr_stream(stream);
     dim3 grid(nblk, (F + QG - 1) / QG);
-    if (view) gallery_scan_f32<true><<<grid, 256, 0, s>>>(Q, G, view, F, N, ws_score, ws_idx);
-    else gallery_scan_f32<false><<<grid, 256, 0, s>>>(Q, G, nullptr, F, N, ws_score, ws_idx);
+    if (view) gallery_scan_f32<true><<<grid, 256, 0, s>>>(Q, G, view, F, N, ws_score, ws_idx, seg_counts, seg_len);
+    else gallery_scan_f32<false><<<grid, 256, 0, s>>>(Q, G, nullptr, F, N, ws_score, ws_idx, seg_counts, seg_len);
     FR_CHECK_LAUNCH("gallery_scan_f32");
-    gallery_reduce<<<fr_cdiv(F, 64), 64, 0, s>>>(ws_score, ws_idx, nblk, F, row_offset, out_idx, out_score);
+    gallery_reduce<<<fr_cdiv(F, 64), 64, 0, s>>>(ws_score, ws_idx, nblk, F, row_offset, out_idx, out_score, seg_counts, seg_len);
     FR_CHECK_LAUNCH("gallery_reduce");
     return FR_OK;
 }
 
 extern "C" int fr_gallery_match_f32(const float* Q, const float* G, int F, int64_t N, int D, int64_t row_offset,
                                     int64_t* out_idx, float* out_score, void* workspace, size_t workspace_bytes,
-                                    fr_stream_t stream) {
+                                    const int32_t* seg_counts, int seg_len, fr_stream_t stream) {
     return gallery_match_launch("fr_gallery_match_f32", Q, G, nullptr, F, N, D, row_offset, out_idx, out_score,
-                                workspace, workspace_bytes, stream);
+                                workspace, workspace_bytes, seg_counts, seg_len, stream);
 }
 
 extern "C" int fr_gallery_match_view_f32(const float* Q, const float* G, const int64_t* view, int F, int64_t Nview,
@@ -154,7 +174,7 @@ extern "C" int fr_gallery_match_view_f32(const float* Q, const float* G, const i
     FR_REQUIRE(view || Nview == 0, "fr_gallery_match_view_f32: null view");
     // Nview == 0: the scan kernel sees no tiles and the reduce writes (-1, -1)
     return gallery_match_launch("fr_gallery_match_view_f32", Q, G, Nview ? view : nullptr, F, Nview, D, 0, out_idx,
-                                out_score, workspace, workspace_bytes, stream);
+                                out_score, workspace, workspace_bytes, nullptr, 0, stream);
 }
 
 // ---------------------------------------------------------------- in-place gallery row update
@@ -240,6 +260,53 @@ extern "C" int fr_match_decide(const int64_t* idx, const float* score, int F, fl
     FR_REQUIRE(idx && score && decision, "fr_match_decide: null pointer");
     match_decide<<<fr_cdiv(F, 256), 256, 0, fr_stream(stream)>>>(idx, score, F, thr, unknown_thr, decision);
     FR_CHECK_LAUNCH("match_decide");
+    return FR_OK;
+}
+
+// ---------------------------------------------------------------- sharded match: exchange payload + reduce
+// SURVEY.md 8(e) step 3.  A candidate travels as three int32 words (score bits, row lo, row hi): the RCCL
+// all-gather moves raw bits, no float conversion kernels in the exchange.  The reduce applies the scan's own
+// rule over the R shards: maximum score, lowest global row on exact ties; (-1, -1.0) when no shard has a row.
+__global__ void match_pack_candidates(const int64_t* __restrict__ idx, const float* __restrict__ score, int n,
+                                      int32_t* __restrict__ cand) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = idx[i];
+    cand[i * 3 + 0] = __float_as_int(score[i]);
+    cand[i * 3 + 1] = (int32_t)(r & 0xffffffffll);
+    cand[i * 3 + 2] = (int32_t)(r >> 32);
+}
+
+__global__ void match_reduce_shards(const int32_t* __restrict__ cand, int R, int n, int q0, int F,
+                                    int64_t* __restrict__ out_idx, float* __restrict__ out_score) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    float bs = -INFINITY; int64_t bi = -1;
+    for (int r = 0; r < R; ++r) {
+        const int32_t* c = cand + ((int64_t)r * n + q0 + f) * 3;
+        const int64_t i = (int64_t)(((uint64_t)(uint32_t)c[2] << 32) | (uint32_t)c[1]);
+        if (i >= 0) take_better(bs, bi, __int_as_float(c[0]), i);
+    }
+    if (bi < 0) { out_idx[f] = -1; out_score[f] = -1.0f; }
+    else { out_idx[f] = bi; out_score[f] = bs; }
+}
+
+extern "C" int fr_match_pack_candidates(const int64_t* idx, const float* score, int n, int32_t* cand,
+                                        fr_stream_t stream) {
+    if (n <= 0) return FR_OK;
+    FR_REQUIRE(idx && score && cand, "fr_match_pack_candidates: null pointer");
+    match_pack_candidates<<<fr_cdiv(n, 256), 256, 0, fr_stream(stream)>>>(idx, score, n, cand);
+    FR_CHECK_LAUNCH("match_pack_candidates");
+    return FR_OK;
+}
+
+extern "C" int fr_match_reduce_shards(const int32_t* cand, int R, int n, int q0, int F, int64_t* out_idx,
+                                      float* out_score, fr_stream_t stream) {
+    FR_REQUIRE(R >= 1 && n >= 0 && q0 >= 0 && F >= 0 && q0 + F <= n, "fr_match_reduce_shards: bad range (R %d n %d q0 %d F %d)", R, n, q0, F);
+    if (F == 0) return FR_OK;
+    FR_REQUIRE(cand && out_idx && out_score, "fr_match_reduce_shards: null pointer");
+    match_reduce_shards<<<fr_cdiv(F, 256), 256, 0, fr_stream(stream)>>>(cand, R, n, q0, F, out_idx, out_score);
+    FR_CHECK_LAUNCH("match_reduce_shards");
     return FR_OK;
 }
 
@@ -367,193 +434,5 @@ extern "C" int fr_mean_rows_f32(const float* x, int K, int D, float* out, fr_str
     FR_REQUIRE(x && out && K > 0 && D > 0, "fr_mean_rows_f32: bad argument");
     mean_rows<<<fr_cdiv(D, 256), 256, 0, fr_stream(stream)>>>(x, K, D, out);
     FR_CHECK_LAUNCH("mean_rows");
-    return FR_OK;
-}
-
-// ---------------------------------------------------------------- f16 gallery scan + exact f32 re-rank
-// For 1 M .. 10 M row galleries (BASELINE configs C4/C5) the scan runs on the f16 matrix cores over an f16
-// copy of the gallery (half the HBM bytes of the f32 rows, 16x the f32 matrix rate):
-// v_mfma_f32_32x32x16_f16 with A = 32 gallery rows, B = 32 queries, so (as in the f32 scan) a lane owns one
-// query and 16 rows per tile and keeps its top-FR_TOPK candidates locally.  The per-block candidates are then
-// merged and RE-SCORED EXACTLY in f32 against the f32 rows; the final pick is max f32 score, lowest row on
-// ties - the reference's rule - so f16 rounding can only matter if the true winner fell out of the f16 top-4.
-#define QG16 2            // query groups (of 32) per pass: 64 queries share one sweep; 66 KB LDS -> 2 blocks/CU
-
-struct Top4 { float s[FR_TOPK]; int i[FR_TOPK]; };
-
-__device__ __forceinline__ void top4_insert(Top4& t, float s, int i) {
-    // candidates arrive in ascending row order within a lane: strict '>' keeps the earlier row on ties.
-    // Static indices only (a runtime-indexed store would push the lists to scratch memory).
-    if (!(s > t.s[FR_TOPK - 1])) return;
-    t.s[FR_TOPK - 1] = s; t.i[FR_TOPK - 1] = i;
-#pragma unroll
-    for (int k = FR_TOPK - 1; k > 0; --k) {
-        const bool up = t.s[k] > t.s[k - 1];
-        const float hs = up ? t.s[k] : t.s[k - 1], ls = up ? t.s[k - 1] : t.s[k];
-        const int hi = up ? t.i[k] : t.i[k - 1], li = up ? t.i[k - 1] : t.i[k];
-        t.s[k - 1] = hs; t.s[k] = ls; t.i[k - 1] = hi; t.i[k] = li;
-    }
-}
-
-__global__ __launch_bounds__(256) void gallery_scan_f16(const float* __restrict__ Q, const half_t* __restrict__ G,
-                                                        int F, int64_t N, float* __restrict__ ws_score,
-                                                        int* __restrict__ ws_idx) {
-    extern __shared__ __attribute__((aligned(16))) half_t qh[];       // [QG16*32][520] halves (row pad 16 B)
-    constexpr int QP = GD + 8;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q0 = blockIdx.y * (QG16 * 32);
-    for (int e = tid; e < QG16 * 32 * (GD / 4); e += 256) {
-        const int r = e / (GD / 4), c = e - r * (GD / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q0 + r < F) v = *reinterpret_cast<const float4*>(Q + (int64_t)(q0 + r) * GD + c * 4);
-        half4 h = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
-        *reinterpret_cast<half4*>(qh + r * QP + c * 4) = h;
-    }
-    __syncthreads();
-    const int r = lane & 31, h = lane >> 5;
-    Top4 top[QG16];
-#pragma unroll
-    for (int g = 0; g < QG16; ++g)
-#pragma unroll
-        for (int k = 0; k < FR_TOPK; ++k) { top[g].s[k] = -INFINITY; top[g].i[k] = -1; }
-    const int64_t ntiles = (N + 31) / 32;
-    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
-        const int64_t row = t * 32 + r;
-        const bool ok = row < N;
-        const half_t* gp = G + (ok ? row : 0) * GD + 8 * h;
-        float16v acc[QG16];
-#pragma unroll
-        for (int g = 0; g < QG16; ++g)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
-        // the tile's 32 x 1 KB rows are fetched as two bursts of 16 independent 16-byte loads per lane
-        // (memory-level parallelism: a dependent load per MFMA step left the scan latency-bound at 0.8 TB/s)
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            half8 a[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                a[u] = *reinterpret_cast<const half8*>(gp + (half * 16 + u) * 16);
-                if (!ok) a[u] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int kk = half * 16 + u;
-#pragma unroll
-                for (int g = 0; g < QG16; ++g) {
-                    const half8 b = *reinterpret_cast<const half8*>(qh + (g * 32 + r) * QP + kk * 16 + 8 * h);
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u], b, acc[g], 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < QG16; ++g)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int64_t gi = t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                if (gi < N) top4_insert(top[g], acc[g][reg], (int)gi);
-            }
-    }
-    // every (block, wave, half) writes its candidates; the re-rank kernel merges them
-    const int slots = gridDim.x * 8;                               // candidate lists per query
-    const int slot = (blockIdx.x * 4 + wave) * 2 + h;
-#pragma unroll
-    for (int g = 0; g < QG16; ++g) {
-        const int q = q0 + g * 32 + r;
-        if (q < F) {
-#pragma unroll
-            for (int k = 0; k < FR_TOPK; ++k) {
-                ws_score[((int64_t)q * slots + slot) * FR_TOPK + k] = top[g].s[k];
-                ws_idx[((int64_t)q * slots + slot) * FR_TOPK + k] = top[g].i[k];
-            }
-        }
-    }
-}
-
-// one wave per query: merge the candidate lists (f16 scores), keep the best FR_TOPK, re-score them in f32
-__global__ __launch_bounds__(64) void gallery_rerank(const float* __restrict__ Q, const float* __restrict__ G32,
-                                                     const float* __restrict__ ws_score, const int* __restrict__ ws_idx,
-                                                     int F, int ncand, int64_t row_offset, int64_t* __restrict__ out_idx,
-                                                     float* __restrict__ out_score) {
-    const int q = blockIdx.x, lane = threadIdx.x;
-    float bs[FR_TOPK]; int bi[FR_TOPK];
-#pragma unroll
-    for (int k = 0; k < FR_TOPK; ++k) { bs[k] = -INFINITY; bi[k] = -1; }
-    // FR_TOPK rounds of wave-wide argmax over the candidates (ties -> lowest row), removing the winner each time
-    for (int round = 0; round < FR_TOPK; ++round) {
-        float ms = -INFINITY; int mi = 0x7fffffff;
-        for (int c = lane; c < ncand; c += 64) {
-            const float s = ws_score[(int64_t)q * ncand + c];
-            const int i = ws_idx[(int64_t)q * ncand + c];
-            bool taken = i < 0;
-#pragma unroll
-            for (int k = 0; k < FR_TOPK; ++k) taken |= (k < round && bi[k] == i);
-            if (!taken && (s > ms || (s == ms && i < mi))) { ms = s; mi = i; }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float os = __shfl_xor(ms, o, 64); const int oi = __shfl_xor(mi, o, 64);
-            if (os > ms || (os == ms && oi < mi)) { ms = os; mi = oi; }
-        }
-        bs[round] = ms; bi[round] = (mi == 0x7fffffff) ? -1 : mi;
-    }
-    float best = -INFINITY; int besti = -1;
-#pragma unroll
-    for (int k = 0; k < FR_TOPK; ++k) {
-        if (bi[k] < 0) continue;
-        float s = bs[k];
-        if (G32) {                                                 // exact f32 dot
-            const float* g = G32 + (int64_t)bi[k] * GD;
-            const float* qq = Q + (int64_t)q * GD;
-            float p = 0.f;
-            for (int c = lane * 4; c < GD; c += 256) {
-                const float4 a = *reinterpret_cast<const float4*>(qq + c), b = *reinterpret_cast<const float4*>(g + c);
-                p += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
-            }
-            s = wave_sum(p);
-        }
-        if (s > best || (s == best && bi[k] < besti)) { best = s; besti = bi[k]; }
-    }
-    if (lane == 0) {
-        if (besti < 0 || !(best > -1.0f)) { out_idx[q] = -1; out_score[q] = -1.0f; }
-        else { out_idx[q] = besti + row_offset; out_score[q] = best; }
-    }
-}
-
-static int scan16_blocks(int64_t N) {
-    int64_t b = ((N + 31) / 32 + 3) / 4;
-    if (b < 1) b = 1;
-    if (b > 512) b = 512;
-    return (int)b;
-}
-
-extern "C" size_t fr_gallery_match_f16_workspace(int F, int64_t N) {
-    return (size_t)(F > 0 ? F : 1) * scan16_blocks(N) * 8 * FR_TOPK * 8 + 256;
-}
-
-extern "C" int fr_gallery_match_f16(const float* Q, const void* G16, const float* G32, int F, int64_t N, int D,
-                                    int64_t row_offset, int64_t* out_idx, float* out_score, void* workspace,
-                                    size_t workspace_bytes, fr_stream_t stream) {
-    FR_REQUIRE(D == GD, "fr_gallery_match_f16: D must be %d (got %d)", GD, D);
-    FR_REQUIRE(F >= 0 && N >= 0 && N < (1ll << 31), "fr_gallery_match_f16: bad size");
-    if (F == 0) return FR_OK;
-    FR_REQUIRE(Q && out_idx && out_score && (G16 || N == 0), "fr_gallery_match_f16: null pointer");
-    FR_REQUIRE(workspace && workspace_bytes >= fr_gallery_match_f16_workspace(F, N), "fr_gallery_match_f16: workspace too small");
-    hipStream_t s = fr_stream(stream);
-    const int nblk = scan16_blocks(N), ncand = nblk * 8 * FR_TOPK;
-    float* ws_score = reinterpret_cast<float*>(workspace);
-    int* ws_idx = reinterpret_cast<int*>(ws_score + (size_t)F * ncand);
-    const size_t lds = (size_t)QG16 * 32 * (GD + 8) * sizeof(half_t);            // 66.5 KB
-    static bool done = false;
-    if (!done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gallery_scan_f16), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) { fr_set_error("fr_gallery_match_f16: cannot raise dynamic LDS"); return FR_E_LAUNCH; }
-        done = true;
-    }
-    dim3 grid(nblk, (F + QG16 * 32 - 1) / (QG16 * 32));
-    gallery_scan_f16<<<grid, 256, lds, s>>>(Q, reinterpret_cast<const half_t*>(G16), F, N, ws_score, ws_idx);
-    FR_CHECK_LAUNCH("gallery_scan_f16");
-    gallery_rerank<<<F, 64, 0, s>>>(Q, G32, ws_score, ws_idx, F, ncand, row_offset, out_idx, out_score);
-    FR_CHECK_LAUNCH("gallery_rerank");
     return FR_OK;
 }

@@ -2,18 +2,25 @@
 row-sharded, and one exchange step joins them.
 
 The reference's only parallelism is one OS process per camera, each scanning the whole gallery
-(/root/reference/infrenceServer.py:606,641-646).  Here:
+(/root/reference/infrenceServer.py:606,641-646).  Here, per step:
 
-  1. all-gather of the per-rank query rows, padded to ``q_max`` with a count  (RCCL over xGMI;
-     payload is KBs, so it is latency-bound: one collective, no bucketing);
-  2. every rank scans ITS gallery shard for ALL gathered queries (one HBM pass over the shard);
-  3. all-gather of the per-shard (score, global row) pairs; each rank reduces the candidates of
-     its own queries: maximum score, lowest global row on exact ties - the same rule as the
-     single-GPU scan (strict '>' in /root/reference/infrenceServer.py:538-542).
+  0. every rank re-normalises ITS OWN query rows (a-6, /root/reference/infrenceServer.py:532) - before the
+     exchange, so zero padding rows are never divided by their norm;
+  1. ONE all-gather of the per-rank query rows, padded to ``q_max``, the count riding in an extra row
+     (RCCL over xGMI; the payload is KBs, so it is latency-bound: one collective, no bucketing);
+  2. every rank scans ITS gallery shard for the gathered queries (one HBM pass over the shard); the gathered
+     counts tell the scan which query slots are padding (``counts`` / ``seg_len`` of the scan ops);
+  3. ONE all-gather of the per-shard candidates, packed as int32 (score bits, row lo, row hi); each rank
+     reduces the candidates of its own queries: maximum score, lowest global row on exact ties - the same
+     rule as the single-GPU scan (strict '>' in /root/reference/infrenceServer.py:538-542).
 
-``local_scan(Q[F,512]) -> (idx int64[F] global rows or -1, score f32[F])`` is injected: the
-product passes the HIP scan (GalleryMatcher.match_device with row_offset), the CPU ``gloo`` tests
-pass the oracle.  This module contains no arithmetic besides the final max/tie reduce.
+The arithmetic is injected as an ``ops`` object: ``HipOps`` (the product: libfrhip.so kernels through
+``GalleryMatcher``; fails without a HIP device) or, in the CPU ``gloo`` tests, an oracle-backed stand-in with
+the same four methods.  This module itself only moves bytes.
+
+Query rows travel as f32 (2 KB/row), not f16: the scan's final scores are exact f32 dots of the SAME f32
+query the single-GPU path uses, which is what keeps top-1 ids bit-identical to the CPU loop; at 256 faces
+per rank the collective is 512 KB, far below where xGMI bandwidth (not latency) would matter.
 """
 import torch
 import torch.distributed as dist
@@ -26,9 +33,20 @@ def shard_rows(n_rows, world_size, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def pack_candidates(idx, score):
+    """(idx i64[n], score f32[n]) -> int32 [n,3] = (score bits, row lo, row hi).  Torch form of
+    fr_match_pack_candidates: used by the CPU gloo tests and as the cross-check of the kernel."""
+    n = score.shape[0]
+    pair = torch.empty((n, 3), dtype=torch.int32, device=score.device)
+    pair[:, 0] = score.contiguous().view(torch.int32)
+    pair[:, 1:] = idx.contiguous().view(torch.int32).view(n, 2)
+    return pair
+
+
 def reduce_candidates(scores, idx):
     """scores f32 [R,F], idx i64 [R,F] (global rows, -1 = none) -> best (idx[F], score[F]):
-    maximum score, lowest row index on exact ties; (-1, -1.0) when no shard has a candidate."""
+    maximum score, lowest row index on exact ties; (-1, -1.0) when no shard has a candidate.
+    Torch form of fr_match_reduce_shards (CPU gloo tests, cross-check of the kernel)."""
     valid = idx >= 0
     s = torch.where(valid, scores, torch.full_like(scores, float("-inf")))
     best = s.max(dim=0).values
@@ -39,42 +57,84 @@ def reduce_candidates(scores, idx):
     return torch.where(none, torch.full_like(bi, -1), bi), torch.where(none, torch.full_like(best, -1.0), best)
 
 
+def reduce_packed(allp, world, n, q0, F):
+    """Torch reduce of gathered packed candidates int32 [world*n,3] for queries [q0, q0+F)."""
+    mine = allp.view(world, n, 3)[:, q0:q0 + F]
+    sc = torch.empty((world, F), dtype=torch.int32, device=allp.device).copy_(mine[..., 0]).view(torch.float32)
+    ix = torch.empty((world, F, 2), dtype=torch.int32, device=allp.device).copy_(mine[..., 1:]).view(torch.int64)
+    ix = ix.reshape(world, F)
+    return reduce_candidates(sc, ix)
+
+
+class HipOps:
+    """The product's arithmetic for the exchange: libfrhip.so kernels on this rank's GPU."""
+
+    def __init__(self, matcher, row_lo):
+        from . import _lib
+        self._lib, self.lib = _lib, matcher.lib
+        self.matcher, self.row_lo, self.device = matcher, int(row_lo), matcher.device
+
+    def renormalise(self, Q):
+        out = torch.empty_like(Q)
+        if Q.shape[0]:
+            with torch.cuda.device(self.device):
+                self.lib.fr_l2norm_rows_f32(self._lib.ptr(Q), self._lib.ptr(out), Q.shape[0], Q.shape[1],
+                                            self._lib.stream_ptr())
+        return out
+
+    def scan(self, Q, counts=None, seg_len=0):
+        """Q: unit query rows f32 [n,512]; returns global rows (shard row + row_lo) or -1."""
+        return self.matcher.match_device(Q, renormalise=False, row_offset=self.row_lo, counts=counts, seg_len=seg_len)
+
+    def pack(self, idx, score):
+        n = score.shape[0]
+        cand = torch.empty((n, 3), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            self.lib.fr_match_pack_candidates(self._lib.ptr(idx), self._lib.ptr(score), n, self._lib.ptr(cand),
+                                              self._lib.stream_ptr())
+        return cand
+
+    def reduce(self, allp, world, n, q0, F):
+        idx = torch.empty(F, dtype=torch.int64, device=self.device)
+        score = torch.empty(F, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self.lib.fr_match_reduce_shards(self._lib.ptr(allp), world, n, q0, F, self._lib.ptr(idx),
+                                            self._lib.ptr(score), self._lib.stream_ptr())
+        return idx, score
+
+
 class ShardedGalleryMatcher:
-    def __init__(self, local_scan, q_max, dim=512, group=None, force_exchange=False):
-        """``force_exchange``: run both collectives even with one rank (rehearses the RCCL path on a 1-GPU box)."""
-        self.local_scan, self.q_max, self.dim, self.group = local_scan, q_max, dim, group
+    def __init__(self, ops, q_max, dim=512, group=None, force_exchange=False):
+        """``ops``: renormalise / scan / pack / reduce (``HipOps`` in the product).
+        ``force_exchange``: run both collectives even with one rank (rehearses the RCCL path on a 1-GPU box)."""
+        self.ops, self.q_max, self.dim, self.group = ops, q_max, dim, group
         self.force_exchange = force_exchange
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
     def match(self, Q):
-        """Q f32 [F_local,dim] on this rank's device (F_local <= q_max).
+        """Q f32 [F_local,dim] ``normed_embedding`` rows on this rank's device (F_local <= q_max).
         Returns (idx i64[F_local] global rows, score f32[F_local]) for the local queries."""
         F = Q.shape[0]
         assert F <= self.q_max, "more local queries than q_max"
+        Qn = self.ops.renormalise(Q.to(torch.float32).contiguous())
         if self.world == 1 and not self.force_exchange:
-            return self.local_scan(Q)
+            return self.ops.scan(Qn)
         dev = Q.device
         # (1) gather queries; the count rides in an extra row so it stays ONE collective
         send = torch.zeros((self.q_max + 1, self.dim), dtype=torch.float32, device=dev)
-        send[:F] = Q
+        send[:F] = Qn
         send[self.q_max:, :1].fill_(float(F))     # (a scalar __setitem__ copies from the host and SYNCHRONISES)
         allq = torch.empty((self.world * (self.q_max + 1), self.dim), dtype=torch.float32, device=dev)
         dist.all_gather_into_tensor(allq, send, group=self.group)      # concatenated along dim 0
         allq = allq.view(self.world, self.q_max + 1, self.dim)
-        # (2) scan the local shard for every gathered query (padding rows included: fixed shape)
+        counts = allq[:, self.q_max, 0].to(torch.int32).contiguous()   # gathered face counts, on the device
+        # (2) scan the local shard for every gathered query slot (fixed shape; slots >= count are skipped by the scan)
         flat = allq[:, :self.q_max].reshape(self.world * self.q_max, self.dim)
-        idx, score = self.local_scan(flat)
-        # (3) gather the per-shard candidates and reduce those of the local queries.  (score, row) travel as raw
-        # bits in ONE int32 [n,3] tensor: bit copies only, no float conversion kernels in the exchange
+        idx, score = self.ops.scan(flat, counts=counts, seg_len=self.q_max)
+        # (3) gather the per-shard candidates and reduce those of the local queries
         n = score.shape[0]
-        pair = torch.empty((n, 3), dtype=torch.int32, device=dev)
-        pair[:, 0] = score.contiguous().view(torch.int32)
-        pair[:, 1:] = idx.contiguous().view(torch.int32).view(n, 2)
+        pair = self.ops.pack(idx, score)
         allp = torch.empty((self.world * n, 3), dtype=torch.int32, device=dev)
         dist.all_gather_into_tensor(allp, pair, group=self.group)
-        mine = allp.view(self.world, n, 3)[:, self.rank * self.q_max:self.rank * self.q_max + F]
-        sc = torch.empty((self.world, F), dtype=torch.int32, device=dev).copy_(mine[..., 0]).view(torch.float32)
-        ix = torch.empty((self.world, F, 2), dtype=torch.int32, device=dev).copy_(mine[..., 1:]).view(torch.int64)
-        ix = ix.reshape(self.world, F)
-        return reduce_candidates(sc, ix)
+        return self.ops.reduce(allp, self.world, n, self.rank * self.q_max, F)

@@ -79,11 +79,26 @@ class FaceAnalysis:
         _lib.require_gpu()
         self.device = torch.device(f"cuda:{max(int(ctx_id), 0)}")
         rec, det = self._load_states()
+        self._det_states = det
         self.rec = IResNetHIP(rec, self.arch, self.device)
         self.det = MTCNNHIP(*det, device=self.device, **self.det_kwargs)
         self.lib = _lib.load()
         self._use_graphs, self._graphs = False, {}
         return self
+
+    def clone_with(self, **det_kwargs):
+        """A second engine on the same device that SHARES this one's embed network (weights resident once) and
+        has its own detector with other capacities / thresholds (e.g. ``cap_o=1`` for single-face frames)."""
+        from .mtcnn import MTCNNHIP
+        if self.det is None:
+            raise _lib.FrError("FaceAnalysis.prepare() has not been called")
+        other = FaceAnalysis(self.name, self.root, providers=self.providers, arch=self.arch)
+        other.device, other.rec, other.lib, other.synthetic = self.device, self.rec, self.lib, self.synthetic
+        other._det_states = self._det_states
+        other.det_kwargs = {**self.det_kwargs, **det_kwargs}
+        other.det = MTCNNHIP(*self._det_states, device=self.device, **other.det_kwargs)
+        other._use_graphs, other._graphs = False, {}
+        return other
 
     # ------------------------------------------------------------------ device-side pipeline
     def detect_embed_device(self, frames):

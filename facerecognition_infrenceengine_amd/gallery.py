@@ -14,20 +14,28 @@ from . import _lib
 DIM = 512
 
 
+class StaleViewError(_lib.FrError):
+    """A GalleryView was used after its gallery's membership changed: fetch a fresh view and retry."""
+
+
 class GalleryMatcher:
     """``G[N,512]`` float32 unit rows on the device + the id table."""
 
-    def __init__(self, device="cuda:0", f16_scan=False):
-        """``f16_scan``: keep an f16 copy of the rows and scan it on the f16 matrix cores, then re-score the
-        top-4 rows per query exactly in f32 (large galleries / many queries); the f32 rows are kept."""
+    def __init__(self, device="cuda:0", f16_scan=False, scan=None):
+        """``scan``: "f32" (default: exact f32 scan on the f32 matrix cores), "f16" or "f8": keep a 16-bit / 8-bit
+        copy of the rows, scan THAT in one pass on the f16 / fp8 matrix cores for the whole query batch, then
+        re-score the top-4 / top-8 rows per query exactly in f32 (large galleries / many queries: BASELINE
+        configs C4 / C5); the f32 rows are kept.  ``f16_scan=True`` is the older spelling of scan="f16"."""
         _lib.require_gpu()
-        self.f16_scan = f16_scan
-        self.G16 = None
+        self.scan = scan or ("f16" if f16_scan else "f32")
+        if self.scan not in ("f32", "f16", "f8"):
+            raise ValueError("scan must be 'f32', 'f16' or 'f8'")
+        self.f16_scan = self.scan == "f16"
+        self.G16 = None                       # the coarse copy (f16 or fp8 e4m3 x 256)
         self.lib = _lib.load()
         self.device = torch.device(device)
         self.ids = []
         self.G = torch.empty((0, DIM), dtype=torch.float32, device=self.device)
-        self._ws = None
 
     def __len__(self):
         return self.G.shape[0]
@@ -47,20 +55,26 @@ class GalleryMatcher:
         self.ids = list(ids)
         self.G = rows
         self.G16 = None
-        if self.f16_scan and rows.shape[0]:
-            self.G16 = torch.empty(rows.shape, dtype=torch.float16, device=self.device)
+        if self.scan != "f32" and rows.shape[0]:
             with torch.cuda.device(self.device):
-                self.lib.fr_f32_to_f16(_lib.ptr(rows), _lib.ptr(self.G16), rows.numel(), _lib.stream_ptr())
+                if self.scan == "f16":
+                    self.G16 = torch.empty(rows.shape, dtype=torch.float16, device=self.device)
+                    self.lib.fr_f32_to_f16(_lib.ptr(rows), _lib.ptr(self.G16), rows.numel(), _lib.stream_ptr())
+                else:
+                    self.G16 = torch.empty(rows.shape, dtype=torch.uint8, device=self.device)
+                    self.lib.fr_f32_to_f8(_lib.ptr(rows), _lib.ptr(self.G16), rows.numel(), _lib.stream_ptr())
 
-    def _workspace(self, F):
-        need = self.lib.fr_gallery_match_workspace(F, self.G.shape[0])
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+    def _workspace(self, need):
+        """Scratch for ONE scan, taken from torch's caching allocator under the current stream: the block is
+        owned by that stream, so concurrent matches on different streams never share (or free) each other's
+        partial results.  (A per-object buffer did: two pipes driving one matcher overwrote ws_score/ws_idx.)"""
+        return torch.empty(max(int(need), 16), dtype=torch.uint8, device=self.device)
 
-    def match_device(self, Q, renormalise=True, row_offset=0):
+    def match_device(self, Q, renormalise=True, row_offset=0, counts=None, seg_len=0):
         """Q: float32 [F,512] device tensor of ``normed_embedding`` rows.
-        Returns device tensors (idx int64[F] (-1: empty gallery), score float32[F])."""
+        Returns device tensors (idx int64[F] (-1: empty gallery), score float32[F]).
+        ``counts`` (device int32 [F / seg_len]) marks padding slots of a gathered batch (sharded match): slot f
+        is real iff f % seg_len < counts[f // seg_len]; padding costs no scan work and reports (-1, -1)."""
         Q = Q.to(self.device, torch.float32).contiguous().reshape(-1, DIM)
         F = Q.shape[0]
         idx = torch.empty(F, dtype=torch.int64, device=self.device)
@@ -73,17 +87,19 @@ class GalleryMatcher:
                 Qn = torch.empty_like(Q)
                 self.lib.fr_l2norm_rows_f32(_lib.ptr(Q), _lib.ptr(Qn), F, DIM, s)
                 Q = Qn
+            cp = _lib.ptr(counts) if counts is not None else None
+            if counts is not None:
+                assert counts.dtype == torch.int32 and counts.is_contiguous() and seg_len > 0 and F == counts.numel() * seg_len
             if self.G16 is not None:
-                need = self.lib.fr_gallery_match_f16_workspace(F, self.G.shape[0])
-                if self._ws is None or self._ws.numel() < need:
-                    self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-                self.lib.fr_gallery_match_f16(_lib.ptr(Q), _lib.ptr(self.G16), _lib.ptr(self.G), F, self.G.shape[0], DIM,
-                                              row_offset, _lib.ptr(idx), _lib.ptr(score), _lib.ptr(self._ws),
-                                              self._ws.numel(), s)
+                wsz, fn = ((self.lib.fr_gallery_match_f16_workspace, self.lib.fr_gallery_match_f16) if self.scan == "f16"
+                           else (self.lib.fr_gallery_match_f8_workspace, self.lib.fr_gallery_match_f8))
+                ws = self._workspace(wsz(F, self.G.shape[0]))
+                fn(_lib.ptr(Q), _lib.ptr(self.G16), _lib.ptr(self.G), F, self.G.shape[0], DIM, row_offset,
+                   _lib.ptr(idx), _lib.ptr(score), _lib.ptr(ws), ws.numel(), cp, seg_len, s)
                 return idx, score
-            ws = self._workspace(F)
+            ws = self._workspace(self.lib.fr_gallery_match_workspace(F, self.G.shape[0]))
             self.lib.fr_gallery_match_f32(_lib.ptr(Q), _lib.ptr(self.G), F, self.G.shape[0], DIM, row_offset,
-                                          _lib.ptr(idx), _lib.ptr(score), _lib.ptr(ws), ws.numel(), s)
+                                          _lib.ptr(idx), _lib.ptr(score), _lib.ptr(ws), ws.numel(), cp, seg_len, s)
         return idx, score
 
     def decide_device(self, idx, score, thr, unknown_thr=None):
@@ -199,7 +215,6 @@ class GalleryView:
         self.generation = gallery.generation
         self.lib, self.device = gallery.lib, gallery.device
         self.slots = torch.tensor([gallery.slot_of[i] for i in self.ids], dtype=torch.int64, device=self.device)
-        self._ws = None
 
     def __len__(self):
         return len(self.ids)
@@ -211,7 +226,7 @@ class GalleryView:
     def match_device(self, Q, renormalise=True):
         """As ``GalleryMatcher.match_device``; idx is the position in ``self.ids`` (-1: empty view)."""
         if self.generation != self.gallery.generation:
-            raise _lib.FrError("GalleryView is stale: the gallery's membership changed after the view was made")
+            raise StaleViewError("GalleryView is stale: the gallery's membership changed after the view was made")
         Q = Q.to(self.device, torch.float32).contiguous().reshape(-1, DIM)
         F = Q.shape[0]
         idx = torch.empty(F, dtype=torch.int64, device=self.device)
@@ -224,12 +239,10 @@ class GalleryView:
                 Qn = torch.empty_like(Q)
                 self.lib.fr_l2norm_rows_f32(_lib.ptr(Q), _lib.ptr(Qn), F, DIM, s)
                 Q = Qn
-            need = self.lib.fr_gallery_match_workspace(F, len(self.ids))
-            if self._ws is None or self._ws.numel() < need:
-                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            ws = GalleryMatcher._workspace(self, self.lib.fr_gallery_match_workspace(F, len(self.ids)))
             self.lib.fr_gallery_match_view_f32(_lib.ptr(Q), _lib.ptr(self.gallery.G), _lib.ptr(self.slots), F,
                                                len(self.ids), DIM, _lib.ptr(idx), _lib.ptr(score),
-                                               _lib.ptr(self._ws), self._ws.numel(), s)
+                                               _lib.ptr(ws), ws.numel(), s)
         return idx, score
 
     decide_device = GalleryMatcher.decide_device

@@ -7,6 +7,7 @@ ordering, thresholds, capacities) are those written down in ``oracle/detect.py``
 """
 import math
 import os
+import threading
 
 import torch
 
@@ -128,6 +129,7 @@ class MTCNNHIP:
         self.cap_scale, self.keep_scale, self.cap_p, self.cap_r, self.cap_o = cap_scale, keep_scale, cap_p, cap_r, cap_o
         assert cap_scale <= 4096 and cap_p <= 1024 and cap_r <= 1024 and cap_o <= 1024
         self._sides = {}
+        self._tls = threading.local()      # per-thread launch stream: detect_batch is re-entrant across threads
         self._one_stream = os.environ.get("FR_DET_ONE_STREAM") == "1"      # profiling: per-kernel times add up
         d = self.device
         p, r, o = ({k: v.detach().float().cpu() for k, v in s.items()} for s in (pstate, rstate, ostate))
@@ -149,6 +151,14 @@ class MTCNNHIP:
         self.o5 = _MConv(24, _dense_as_conv(o["dense5.weight"], 3, 128), o["dense5.bias"], o["prelu5.weight"], d)
         self.o6 = _MConv(25, torch.cat([o["dense6_1.weight"], o["dense6_2.weight"], o["dense6_3.weight"]]).reshape(16, 256, 1, 1),
                          torch.cat([o["dense6_1.bias"], o["dense6_2.bias"], o["dense6_3.bias"]]), None, d)
+
+    @property
+    def _s(self):
+        return self._tls.s
+
+    @_s.setter
+    def _s(self, v):
+        self._tls.s = v
 
     # ---- thin launch helpers (all on the current stream)
     def _f32(self, *shape):

@@ -175,7 +175,8 @@ class EmbeddingManager:
     # ---- views
     def _company_rows(self, company_id):
         emp, vis = self.store.company_member_ids(company_id)
-        ids = [i for i in emp if i in self.embeddings] + [i for i in vis if i in self.embeddings and i not in emp]
+        seen = set(emp)
+        ids = [i for i in emp if i in self.embeddings] + [i for i in vis if i in self.embeddings and i not in seen]
         return ids
 
     def get_embeddings_for_company(self, company_id):
@@ -250,8 +251,9 @@ class FaceRecognitionProcessor:
         if len(matcher) == 0:
             logger.warning("No embeddings found for company %s", company_id)
             return None
-        r = self.face_detector.detect_embed_device(_to_device(frame, self.face_detector.device))
-        idx, score = matcher.match_device(r["normed_embedding"])             # renormalise + scan (:532-542)
+        r = _detect_embed(self.face_detector, frame)
+        matcher, metadata, idx, score = _match_fresh(self.embedding_manager, company_id, matcher, metadata,
+                                                     r["normed_embedding"])  # renormalise + scan (:532-542)
         dec = matcher.decide_device(idx, score, self.recognition_threshold)  # :545
         idx, score, dec = idx.cpu().numpy(), score.cpu().numpy(), dec.cpu().numpy()
         bbox = r["bbox"].cpu().numpy().astype(int)                           # :531 truncation
@@ -316,8 +318,9 @@ class CameraProcessor:
         timestamp = datetime.utcnow()
         stats = {"faces": 0, "recognized": 0, "unknown": 0}
         try:
-            r = self.face_detector.detect_embed_device(_to_device(frame, self.face_detector.device))
-            idx, score = matcher.match_device(r["normed_embedding"])
+            r = _detect_embed(self.face_detector, frame)
+            matcher, metadata, idx, score = _match_fresh(self.embedding_manager, None, matcher, metadata,
+                                                         r["normed_embedding"])
             dec = matcher.decide_device(idx, score, self.recognition_threshold, self.unknown_threshold).cpu().numpy()
             idx, score = idx.cpu().numpy(), score.cpu().numpy()
             stats["faces"] = len(idx)
@@ -337,6 +340,29 @@ class CameraProcessor:
         except Exception as e:
             logger.error("Error in face detection: %s", e)
         return stats
+
+
+def _detect_embed(detector, frame):
+    """detect -> align -> embed of one frame under the engine's lock: one engine may be shared by threads
+    (/root/reference/trainingServer.py:115,227) and ``get_batch`` takes the same lock."""
+    lock = getattr(detector, "_lock", None)
+    dev = _to_device(frame, detector.device)
+    if lock is None:
+        return detector.detect_embed_device(dev)
+    with lock:
+        return detector.detect_embed_device(dev)
+
+
+def _match_fresh(manager, company_id, matcher, metadata, Q):
+    """Scan through the company's view; a sync on another thread may have changed the slab's membership since the
+    view was fetched (its generation moved on): fetch the current view once and retry instead of dropping the frame."""
+    from .gallery import StaleViewError
+    try:
+        idx, score = matcher.match_device(Q)
+    except StaleViewError:
+        matcher, metadata = manager.get_matcher_for_company(company_id)
+        idx, score = matcher.match_device(Q)
+    return matcher, metadata, idx, score
 
 
 def _to_device(frame, device):

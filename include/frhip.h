@@ -11,7 +11,10 @@
  *     (PyTorch-ROCm tensors in the Python host), passed as plain pointers + sizes;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
  *     launches are asynchronous, nothing synchronises;
- *   - no global mutable state.
+ *   - no global mutable state and no environment variables: the only process-wide state is an atomic
+ *     per-device bit per kernel remembering that its dynamic-LDS limit has been raised there (idempotent);
+ *     diagnostic switches and in-kernel cycle stamps exist only in the separate debug build
+ *     (`make debug` -> libfrhip_debug.so), never in libfrhip.so.
  * Each declaration cites the reference behaviour it replaces.
  */
 #ifndef FRHIP_H
@@ -43,11 +46,15 @@ int fr_l2norm_rows_f32(const float* x, float* out, int rows, int dim, fr_stream_
  *      (infrenceServer.py:535-542, peopleCount.py:866-873).  Rows carry their index as id;
  *      strict '>' => the lowest row index wins exact ties.  Q [F,D] f32 (re-normalised),
  *      G [N,D] f32 row-major, D == 512.  out_idx[f] = row + row_offset (or -1 when N == 0),
- *      out_score[f] = best dot (or -1).  workspace: fr_gallery_match_workspace() bytes. */
+ *      out_score[f] = best dot (or -1).  workspace: fr_gallery_match_workspace() bytes.
+ *      seg_counts (optional, device i32 [F / seg_len]) marks padding: query slot f is real iff
+ *      f % seg_len < seg_counts[f / seg_len] (the gathered per-rank face counts of the sharded match, 8(e));
+ *      padding slots cost no scan work and report (-1, -1).  NULL: every slot is real. */
 size_t fr_gallery_match_workspace(int F, int64_t N);
 int fr_gallery_match_f32(const float* Q, const float* G, int F, int64_t N, int D,
                          int64_t row_offset, int64_t* out_idx, float* out_score,
-                         void* workspace, size_t workspace_bytes, fr_stream_t stream);
+                         void* workspace, size_t workspace_bytes, const int32_t* seg_counts, int seg_len,
+                         fr_stream_t stream);
 /* Gallery slab + views (replaces the per-frame dict filtering of
  * infrenceServer.py:343-380 and the dict inserts/deletes of :260-341, :234-258).  G is one device-resident
  * slab of row slots [capacity,512]; a view is the int64 slot list of one company in the reference's dict
@@ -59,14 +66,27 @@ int fr_gallery_match_view_f32(const float* Q, const float* G, const int64_t* vie
                               fr_stream_t stream);
 int fr_gallery_update_rows_f32(float* G, const int64_t* slots, const float* rows, int n, int D, int normalise,
                                fr_stream_t stream);
-/* f16 gallery (1 M .. 10 M rows): coarse scan on the f16 matrix cores keeps the top FR_TOPK rows per
- * query, which are then re-scored exactly in f32 against G32 (may be NULL: scores then come from the
- * f16 scan) and picked by max score / lowest row.  G16: f16 [N,512] (fr_f32_to_f16 of the unit rows). */
+/* Large galleries / many queries (BASELINE configs C4, C5): ONE pass over a 16-bit or 8-bit copy of the gallery
+ * on the f16 / fp8 matrix cores for up to 256 queries per block keeps the top FR_TOPK (f16) / FR_TOPK8 (fp8)
+ * rows per query, which are then re-scored EXACTLY in f32 against G32 (may be NULL: scores then come from the
+ * coarse scan) and picked by max score / lowest row - the rule of infrenceServer.py:535-542.
+ * G16: f16 [N,512] (fr_f32_to_f16 of the unit rows); G8: OCP fp8 e4m3 [N,512] scaled by FR_F8_SCALE
+ * (fr_f32_to_f8).  seg_counts / seg_len: see fr_gallery_match_f32. */
 #define FR_TOPK 4
+#define FR_TOPK8 8
+#define FR_F8_SCALE 256.0f
 size_t fr_gallery_match_f16_workspace(int F, int64_t N);
 int fr_gallery_match_f16(const float* Q, const void* G16, const float* G32, int F, int64_t N, int D,
                          int64_t row_offset, int64_t* out_idx, float* out_score,
-                         void* workspace, size_t workspace_bytes, fr_stream_t stream);
+                         void* workspace, size_t workspace_bytes, const int32_t* seg_counts, int seg_len,
+                         fr_stream_t stream);
+size_t fr_gallery_match_f8_workspace(int F, int64_t N);
+int fr_gallery_match_f8(const float* Q, const void* G8, const float* G32, int F, int64_t N, int D,
+                        int64_t row_offset, int64_t* out_idx, float* out_score,
+                        void* workspace, size_t workspace_bytes, const int32_t* seg_counts, int seg_len,
+                        fr_stream_t stream);
+/* f32 -> fp8 e4m3 row conversion (x * FR_F8_SCALE, round to nearest even, n % 4 == 0) */
+int fr_f32_to_f8(const float* x, void* out, int64_t n, fr_stream_t stream);
 /* f32 -> f16 row conversion for building the device-resident gallery (infrenceServer.py:271) */
 int fr_f32_to_f16(const float* x, void* out, int64_t n, fr_stream_t stream);
 /* a-8  known = best_id and best >= thr  (infrenceServer.py:545; peopleCount.py:876-882):
@@ -74,6 +94,17 @@ int fr_f32_to_f16(const float* x, void* out, int64_t n, fr_stream_t stream);
  *      pass unknown_thr = thr for the live path). */
 int fr_match_decide(const int64_t* idx, const float* score, int F, float thr, float unknown_thr,
                     int32_t* decision, fr_stream_t stream);
+
+
+/* e   Sharded match (the reference's only parallelism is one process per camera, each scanning
+ *      the whole gallery: infrenceServer.py:606,641-646).  Every rank scans ITS gallery row shard for all gathered
+ *      queries (fr_gallery_match_* with row_offset = the shard's first global row); candidates travel as
+ *      int32 [n][3] = (score bits, row lo, row hi) so the all-gather moves raw bits; the reduce over the R shards
+ *      for queries [q0, q0+F) applies the scan's own rule - maximum score, lowest global row on exact ties,
+ *      (-1, -1.0) when no shard has a candidate (infrenceServer.py:535-542).  cand_all: int32 [R][n][3]. */
+int fr_match_pack_candidates(const int64_t* idx, const float* score, int n, int32_t* cand, fr_stream_t stream);
+int fr_match_reduce_shards(const int32_t* cand_all, int R, int n, int q0, int F, int64_t* out_idx,
+                           float* out_score, fr_stream_t stream);
 
 
 /* ------------------------------------------------- enrolment / clustering consumers of the scan ----

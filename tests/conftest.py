@@ -11,6 +11,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "spawns: starts child processes that use the GPU; scheduled before every other "
+                                       "test, while this process has not initialised the GPU yet")
+
+
+def pytest_collection_modifyitems(config, items):
+    """Tests that start GPU child processes run first: on the GPU pool a process that has initialised the GPU must
+    not exec another program, and forked children of such a process are refused too."""
+    items.sort(key=lambda it: 0 if it.get_closest_marker("spawns") else 1)
 
 
 @pytest.fixture(scope="session")

@@ -35,7 +35,7 @@ def test_invalid_arguments_return_error_not_crash():
     from facerecognition_infrenceengine_amd import _lib
     lib = _lib.load()
     with pytest.raises(_lib.FrError, match="D must be 512"):
-        lib.fr_gallery_match_f32(None, None, 1, 10, 256, 0, None, None, None, 0, None)
+        lib.fr_gallery_match_f32(None, None, 1, 10, 256, 0, None, None, None, 0, None, 0, None)
     with pytest.raises(_lib.FrError):
         lib.fr_l2norm_rows_f32(None, None, 4, 7, None)
     with pytest.raises(_lib.FrError, match="null view"):

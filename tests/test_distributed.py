@@ -16,6 +16,37 @@ def _free_port():
     return p
 
 
+class OracleOps:
+    """CPU stand-in for distributed.HipOps: the oracle's arithmetic behind the same four methods, so the exchange
+    logic (padding, counts, packing, reduce over shards) is what these gloo tests exercise."""
+
+    def __init__(self, shard, lo):
+        self.shard, self.lo = shard, lo
+
+    def renormalise(self, Q):
+        q = Q.numpy()
+        return torch.from_numpy(np.stack([omatch.renormalise(r) for r in q]).astype(np.float32)) if len(q) else Q.clone()
+
+    def scan(self, Q, counts=None, seg_len=0):
+        q = Q.numpy()
+        assert not np.isnan(q).any(), "padding rows must not be divided by their norm"
+        idx, score = omatch.match_rows_fast(q, self.shard) if len(self.shard) else (
+            np.full(len(q), -1, np.int64), np.full(len(q), -1, np.float32))
+        idx = np.where(idx >= 0, idx + self.lo, -1)
+        if counts is not None:                                    # padding slots report (-1, -1), as the HIP scan
+            pad = (np.arange(len(q)) % seg_len) >= counts.numpy()[np.arange(len(q)) // seg_len]
+            idx[pad], score = -1, np.where(pad, np.float32(-1), score)
+        return torch.from_numpy(idx), torch.from_numpy(score.astype(np.float32))
+
+    def pack(self, idx, score):
+        from facerecognition_infrenceengine_amd.distributed import pack_candidates
+        return pack_candidates(idx, score)
+
+    def reduce(self, allp, world, n, q0, F):
+        from facerecognition_infrenceengine_amd.distributed import reduce_packed
+        return reduce_packed(allp, world, n, q0, F)
+
+
 def _worker(rank, world, port, G, Qs, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -23,12 +54,7 @@ def _worker(rank, world, port, G, Qs, out):
     lo, hi = shard_rows(len(G), world, rank)
     shard = G[lo:hi]
 
-    def local_scan(Q):
-        idx, score = omatch.match_rows_fast(Q.numpy(), shard) if len(shard) else (
-            np.full(len(Q), -1, np.int64), np.full(len(Q), -1, np.float32))
-        idx = np.where(idx >= 0, idx + lo, -1)
-        return torch.from_numpy(idx), torch.from_numpy(score)
-    m = ShardedGalleryMatcher(local_scan, q_max=8)
+    m = ShardedGalleryMatcher(OracleOps(shard, lo), q_max=8)
     idx, score = m.match(torch.from_numpy(Qs[rank]))
     out[rank] = (idx.numpy(), score.numpy())
     dist.barrier()

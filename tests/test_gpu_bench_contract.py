@@ -6,7 +6,7 @@ import sys
 
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.spawns]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -18,7 +18,7 @@ def test_bench_prints_one_contract_line():
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "self_check"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "cpu_baseline_1thread", "self_check"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["value"] > 0 and d["unit"] == "faces/s"
     assert d["scaling"] == "weak" and d["higher_is_better"] is True and d["vs_baseline"] is None
@@ -26,3 +26,4 @@ def test_bench_prints_one_contract_line():
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "workload" in d["config"]
+    assert d["cpu_baseline_1thread"]["cores"] == 1 and cb["host_cpu_count"] >= cb["cores"]

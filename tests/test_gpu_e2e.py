@@ -247,3 +247,67 @@ def test_graph_replay_equals_eager(app):
                     assert np.array_equal(a.normed_embedding, b.normed_embedding)
     finally:
         app.enable_graphs(False)
+
+
+def test_model_pack_on_disk_round_trips_through_load_state(app, tmp_path):
+    """The drop-in loads `<root>/models/<name>/arcface_<arch>.{safetensors,pt}` + `mtcnn_{pnet,rnet,onet}.pt`
+    (weights.load_state).  A pack written from the synthetic state dicts must give the synthetic engine's results
+    bit for bit, and the engine must report that it is NOT running on fallback weights."""
+    from safetensors.torch import save_file
+    from facerecognition_infrenceengine_amd import FaceAnalysis, weights
+    from make_golden import synth_frame
+    d = tmp_path / "models" / "mypack"
+    d.mkdir(parents=True)
+    save_file({k: v.contiguous() for k, v in weights.synth_iresnet_state("r100").items()}, str(d / "arcface_r100.safetensors"))
+    for n, st in zip(("pnet", "rnet", "onet"), weights.synth_mtcnn_states()):
+        torch.save({"state_dict": st}, str(d / f"mtcnn_{n}.pt"))              # wrapped form is unwrapped by load_state
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                         # the synthetic-fallback warning must NOT fire
+        b = FaceAnalysis(name="mypack", root=str(tmp_path)).prepare(ctx_id=0)
+    assert b.synthetic is False
+    frame = synth_frame(240, 320, 4)
+    fa, fb = app.get(frame), b.get(frame)
+    assert len(fa) == len(fb) >= 1
+    for x, y in zip(fa, fb):
+        assert np.array_equal(x.embedding, y.embedding) and np.array_equal(x.bbox, y.bbox)
+
+
+def test_processor_threads_share_one_engine_while_the_gallery_syncs(app):
+    """FaceRecognitionProcessor.recognize from 3 threads on ONE engine while another thread keeps force_sync()ing a
+    store whose membership changes: detection runs under the engine lock, a stale company view is re-fetched and
+    retried, so every call returns results (the reference swallows exceptions and would return an unmarked frame)."""
+    import threading
+    from facerecognition_infrenceengine_amd.processor import EmbeddingManager, FaceRecognitionProcessor, InMemoryStore
+    from make_golden import synth_frame
+    rng = np.random.default_rng(3)
+    store = InMemoryStore()
+    for i in range(50):
+        store.add_employee(f"e{i}", "acme", rng.standard_normal(512).astype(np.float32), name=f"E{i}")
+    mgr = EmbeddingManager(store=store, device="cuda:0")
+    proc = FaceRecognitionProcessor(mgr, face_detector=app)
+    frames = [synth_frame(120, 160, s) for s in (1, 2, 3)]
+    ref = [proc.recognize(f, "acme") for f in frames]
+    assert all(r is not None and len(r) >= 1 for r in ref)
+    stop, errors, done = threading.Event(), [], [0, 0, 0]
+
+    def churn():
+        k = 0
+        while not stop.is_set():
+            store.add_employee(f"x{k}", "acme", rng.standard_normal(512).astype(np.float32))   # membership change
+            mgr.force_sync()
+            k += 1
+
+    def work(i):
+        try:
+            for _ in range(12):
+                r = proc.recognize(frames[i], "acme")
+                assert r is not None and len(r) == len(ref[i])
+                assert all(np.array_equal(a["bbox"], b["bbox"]) for a, b in zip(r, ref[i]))
+                done[i] += 1
+        except Exception as e:                                  # noqa: BLE001 - reported below
+            errors.append(repr(e))
+    tc = threading.Thread(target=churn)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    tc.start(); [t.start() for t in ts]; [t.join() for t in ts]
+    stop.set(); tc.join()
+    assert not errors and done == [12, 12, 12], (errors, done)

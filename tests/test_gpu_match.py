@@ -82,9 +82,11 @@ def test_full_size_property_planted_rows(matcher):
         assert float(score.min()) > 0.8
 
 
-@pytest.mark.parametrize("N,F", [(1, 1), (33, 5), (4097, 130), (100_000, 256)])
-def test_f16_scan_with_f32_rerank_matches_f32_oracle(N, F):
-    """f16 coarse scan + exact f32 re-rank must give the SAME ids as the f32 oracle (incl. duplicate rows)."""
+@pytest.mark.parametrize("scan", ["f16", "f8"])
+@pytest.mark.parametrize("N,F", [(1, 1), (33, 5), (63, 300), (4097, 130), (100_000, 256), (20_000, 700)])
+def test_coarse_scan_with_f32_rerank_matches_f32_oracle(N, F, scan):
+    """f16 / fp8 one-pass GEMM scan + exact f32 re-rank must give the SAME ids as the f32 oracle (incl. duplicate
+    rows, a near-duplicate, row tiles that end inside a 64-row tile and query tiles that end inside a wave)."""
     from facerecognition_infrenceengine_amd.gallery import GalleryMatcher
     rng = np.random.default_rng(N * 7 + F)
     G = rng.standard_normal((N, 512)).astype(np.float32); G /= np.linalg.norm(G, axis=1, keepdims=True)
@@ -92,22 +94,81 @@ def test_f16_scan_with_f32_rerank_matches_f32_oracle(N, F):
     if N > 3:
         G[N - 1] = Q[0]; G[N // 2] = Q[0]
         Q[1 % F] = G[N // 3] + 0.01 * rng.standard_normal(512).astype(np.float32)      # near-duplicate of one row
-    m = GalleryMatcher("cuda:0", f16_scan=True)
+    m = GalleryMatcher("cuda:0", scan=scan)
     m.set_rows(list(range(N)), G, normalise=False)
     idx, score = m.match_device(torch.from_numpy(Q).cuda())
     oi, os_ = omatch.match_rows_fast(Q, G)
     assert np.array_equal(idx.cpu().numpy(), oi)
     np.testing.assert_allclose(score.cpu().numpy(), os_, atol=3e-6)                     # scores are the f32 re-scores
+    if N > 3:
+        assert int(idx[0]) == N // 2                                                    # duplicate rows: lowest row
 
 
-def test_f16_scan_full_size_planted_rows():
+@pytest.mark.parametrize("scan,N", [("f16", 1_000_000), ("f8", 1_250_000)])
+def test_coarse_scan_full_size(scan, N):
+    """C4's whole 1 M-row gallery (f16) and one of C5's 10 M / 8 = 1.25 M-row fp8 shards, 2048 gathered queries
+    (8 ranks x 256): planted rows must come back exactly (size-independent property), and for UNPLANTED queries -
+    whose best rows are a near-tie of random rows, the hard case for a coarse scan - the ids must equal those of
+    the exact f32 HIP scan (itself pinned to the oracle at smaller sizes) and of numpy for a few of them."""
     from facerecognition_infrenceengine_amd.gallery import GalleryMatcher
     g = torch.Generator(device="cuda").manual_seed(3)
-    N = 1_000_000
     G = torch.randn((N, 512), generator=g, device="cuda"); G /= G.norm(dim=1, keepdim=True)
     rows = torch.randperm(N, generator=g, device="cuda")[:2048]                        # 8 ranks x 256 gathered queries
     Q = G[rows] + 0.02 * torch.randn((2048, 512), generator=g, device="cuda")
-    m = GalleryMatcher("cuda:0", f16_scan=True)
+    Q[1024:] = torch.randn((1024, 512), generator=g, device="cuda")                    # unknown faces: no planted row
+    m = GalleryMatcher("cuda:0", scan=scan)
     m.set_rows(range(N), G, normalise=False)
     idx, score = m.match_device(Q)
-    assert torch.equal(idx, rows) and float(score.min()) > 0.8
+    assert torch.equal(idx[:1024], rows[:1024]) and float(score[:1024].min()) > 0.8
+    exact = GalleryMatcher("cuda:0")
+    exact.G, exact.ids = m.G, m.ids                                                    # same f32 rows, f32 scan
+    ei, es = exact.match_device(Q[1024:1024 + 256])
+    assert torch.equal(idx[1024:1024 + 256], ei)
+    torch.testing.assert_close(score[1024:1024 + 256], es, atol=3e-6, rtol=0)
+    Qn = Q[1024:1032] / Q[1024:1032].norm(dim=1, keepdim=True)
+    ref = (G @ Qn.T).argmax(dim=0)
+    assert torch.equal(idx[1024:1032], ref)
+
+
+@pytest.mark.parametrize("scan", ["f32", "f16", "f8"])
+def test_padding_slots_are_skipped(scan):
+    """Gathered batch of the sharded match: 4 segments of 8 slots with counts (3, 0, 8, 1); real slots equal the
+    unmasked result, padding slots report (-1, -1) whatever their rows hold (here: NaN)."""
+    from facerecognition_infrenceengine_amd.gallery import GalleryMatcher
+    rng = np.random.default_rng(11)
+    G = rng.standard_normal((3000, 512)).astype(np.float32); G /= np.linalg.norm(G, axis=1, keepdims=True)
+    Q = rng.standard_normal((32, 512)).astype(np.float32); Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    counts = np.array([3, 0, 8, 1], np.int32)
+    real = (np.arange(32) % 8) < counts[np.arange(32) // 8]
+    Qp = Q.copy(); Qp[~real] = np.nan
+    m = GalleryMatcher("cuda:0", scan=scan)
+    m.set_rows(list(range(3000)), G, normalise=False)
+    idx, score = m.match_device(torch.from_numpy(Qp).cuda(), renormalise=False, row_offset=500,
+                                counts=torch.from_numpy(counts).cuda(), seg_len=8)
+    idx, score = idx.cpu().numpy(), score.cpu().numpy()
+    oi, os_ = omatch.match_rows_fast(Q, G)
+    assert np.array_equal(idx[real], oi[real] + 500)
+    np.testing.assert_allclose(score[real], os_[real], atol=3e-6)
+    assert (idx[~real] == -1).all() and (score[~real] == -1).all()
+
+
+def test_two_matches_in_flight_on_two_streams(matcher):
+    """One matcher driven from two HIP streams at once (bench.py --pipes 2): each call owns its scratch, so both
+    results equal their solo runs (a shared per-object workspace let step i's reduce read step i+1's partials)."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    N = 300_000
+    G = torch.randn((N, 512), generator=g, device="cuda"); G /= G.norm(dim=1, keepdim=True)
+    matcher.set_rows(range(N), G, normalise=False)
+    Qa = torch.randn((256, 512), generator=g, device="cuda")
+    Qb = torch.randn((40, 512), generator=g, device="cuda")
+    solo_a, solo_b = matcher.match_device(Qa), matcher.match_device(Qb)
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(4):
+        with torch.cuda.stream(sa):
+            ra = matcher.match_device(Qa)
+        with torch.cuda.stream(sb):
+            rb = matcher.match_device(Qb)
+        torch.cuda.synchronize()
+        assert torch.equal(ra[0], solo_a[0]) and torch.equal(ra[1], solo_a[1])
+        assert torch.equal(rb[0], solo_b[0]) and torch.equal(rb[1], solo_b[1])

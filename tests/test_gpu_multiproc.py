@@ -1,0 +1,46 @@
+"""N > 1 ranks on the one-GPU box: real processes, real collectives (gloo), the HIP scan / pack / reduce kernels as
+the local arithmetic.  Children are started as fresh interpreters; conftest.py runs these tests FIRST, before this
+pytest process has initialised the GPU (a GPU-initialised parent must not exec)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.spawns]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _launch(nproc, script, *args, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script, *args]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+@pytest.mark.parametrize("world,scan", [(2, "f32"), (4, "f16")])
+def test_ranks_over_gloo_with_hip_scan_equal_unsharded_oracle(world, scan):
+    p = _launch(world, os.path.join(ROOT, "tests", "helpers", "sharded_rank.py"), scan)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    assert p.stdout.count(": ok") == world
+
+
+def test_bench_gpus2_launches_itself_and_prints_rank0_line():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: bench.py spawns its ranks itself.  Rehearsal
+    flags: both ranks on cuda:0, gloo instead of RCCL (one device cannot host two RCCL ranks)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo",
+                        "--workload", "C1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and "self_check" in d

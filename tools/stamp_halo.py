@@ -4,6 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 st = torch.zeros(4096 * 8 * 8, dtype=torch.int64, device="cuda")
 os.environ["FR_DBG_STAMPS"] = hex(st.data_ptr())
+# stamps exist only in the diagnostic twin of the library (make -C facerecognition_infrenceengine_amd/csrc debug)
+from facerecognition_infrenceengine_amd import _lib as _fr_lib
+_fr_lib.use_library(os.path.join(os.path.dirname(_fr_lib.LIB_PATH), "libfrhip_debug.so"))
 from tools import bench_conv
 B = 256
 for shape in ((14, 256, 256), (28, 128, 128), (56, 64, 64), (112, 64, 64)):

@@ -4,6 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 st = torch.zeros(4096 * 8 * 4, dtype=torch.int64, device="cuda")
 os.environ["FR_DBG_STAMPS"] = hex(st.data_ptr())
+# stamps exist only in the diagnostic twin of the library (make -C facerecognition_infrenceengine_amd/csrc debug)
+from facerecognition_infrenceengine_amd import _lib as _fr_lib
+_fr_lib.use_library(os.path.join(os.path.dirname(_fr_lib.LIB_PATH), "libfrhip_debug.so"))
 from facerecognition_infrenceengine_amd import weights, _lib
 from facerecognition_infrenceengine_amd.mtcnn import MTCNNHIP
 det = MTCNNHIP(*weights.synth_mtcnn_states(), device="cuda:0")
