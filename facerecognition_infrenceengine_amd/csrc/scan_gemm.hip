@@ -11,13 +11,18 @@
 //     LDS-DMA (buffer_load ... lds, 16 B/lane, whole 128-B lines, XOR-swizzled on the SOURCE side) one tile ahead;
 //     one barrier per tile (2048 MFMA cycles per wave), all 8 waves share the tile: gallery bytes cross L2->LDS once
 //     per 256 queries, and blocks that scan the same row range for other query tiles share an XCD (its L2);
-//   * A = 16 gallery rows, B = 16 queries: a lane owns query (n*16 + lane&15) and rows (m*16 + 4*(lane>>4) + reg), so the
-//     running top-K per query is LANE-LOCAL (registers), candidates arrive in ascending row order, strict '>' keeps
-//     the earlier row on ties.  No cross-lane work inside the scan.
-// Re-rank (gallery_rerank<K>): one wave per query merges the candidate lists, keeps the best K coarse scores and
-//   re-scores those rows EXACTLY in f32 against the f32 rows; final pick = max f32 score, lowest row.  Coarse
-//   rounding can only matter if the true winner fell out of the coarse top-K (K = 4 for f16, 8 for fp8: the fp8
-//   score error is ~2e-3, the gap to the K-th best of 10^6..10^7 random rows is 7 sigma of it; the tests count).
+//   * A = 16 gallery rows, B = 16 queries: a lane owns query (n*16 + lane&15) and rows (m*16 + 4*(lane>>4) + reg): one
+//     accumulator quad = 4 CONSECUTIVE gallery rows (a "group", id = row / 4) of one query.  The candidates kept are
+//     GROUPS: the running top-K of group maxima per query is LANE-LOCAL (registers), groups arrive in ascending
+//     order, strict '>' keeps the earlier group on ties.  Per tile and query the common path is a max tree over the
+//     lane's 16 scores and one compare (in-kernel ablation: inserting every row into per-lane row lists cost 30 % of
+//     the f16 scan and 60 % of the fp8 scan - 128 slowly warming lists per wave mean a list insert in nearly every
+//     tile).  No cross-lane work inside the scan.
+// Re-rank (gallery_rerank<K>): one wave per query merges the candidate lists, keeps the K groups with the best coarse
+//   maxima and re-scores their 4 rows each EXACTLY in f32 against the f32 rows; final pick = max f32 score, lowest
+//   row.  Coarse rounding can only matter if the true winner's group fell out of the coarse top-K groups (K = 4 for
+//   f16, 8 for fp8: the fp8 score error is ~2e-3, the gap to the K-th best of 10^6..10^7 random rows is 7 sigma of
+//   it; the tests count); near-duplicate neighbouring rows share a group and cannot crowd each other out.
 // Algorithmic bytes: N * 512 * b per pass per 256 queries (b = 2 / 1); FLOP: 2 * N * F * 512.
 #include "common.h"
 
@@ -58,6 +63,7 @@ struct ScanP {
     float* ws_score; int* ws_idx;                       // [F][nranges*4][K]
     const int32_t* seg_counts; int seg_len;
     float qscale;                                       // fp8: queries are multiplied by this before conversion
+    int abl;                                            // debug build only (FR_SCAN_ABL): 1 no epilogue, 2 one DMA only, 4 no MFMA
 };
 
 __device__ __forceinline__ int4v sg_pack_f16(const float* q) {
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(512, 2) void gallery_gemm_scan(ScanP p) {
     for (int t = 0; t < ntiles; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's pieces of tile t have landed
         __builtin_amdgcn_s_barrier();                               // everyone's have; buffer (t+1)&1 is free again
-        if (t + 1 < ntiles) issue_tile(t + 1);
+        if (t + 1 < ntiles && !(FR_DEBUG && (p.abl & 2))) issue_tile(t + 1);
         const char* buf = lds + (t & 1) * TILE_B;
         float4v acc[4][2];
 #pragma unroll
@@ -186,6 +192,11 @@ __global__ __launch_bounds__(512, 2) void gallery_gemm_scan(ScanP p) {
                 const char* rowp = buf + (kc * SG_ROWS + m * 16) * 128;
                 alo[m] = *reinterpret_cast<const int4v*>(rowp + a_lo);
                 ahi[m] = *reinterpret_cast<const int4v*>(rowp + a_hi);
+            }
+            if (FR_DEBUG && (p.abl & 4)) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { acc[m][0][0] += __int_as_float(alo[m][0]); acc[m][1][0] += __int_as_float(ahi[m][0]); }
+                continue;
             }
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -204,21 +215,32 @@ __global__ __launch_bounds__(512, 2) void gallery_gemm_scan(ScanP p) {
                     }
                 }
         }
-        // acc[m][n][reg] = coarse score(row t*64 + m*16 + 4*fq + reg, query q0w + n*16 + fr); rows ascend in (m, reg)
+        // acc[m][n] = coarse scores of the 4-row group (t*64 + m*16 + 4*fq)/4 for query q0w + n*16 + fr; groups ascend in m
+        if (FR_DEBUG && (p.abl & 1)) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) top[n].s[0] = fmaxf(top[n].s[0], acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3]);
+            continue;
+        }
         const int rbase = t * SG_ROWS + 4 * fq;
+        if (t == ntiles - 1) {                                       // rows past the range end read as zeros: not candidates
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    if (rbase + m * 16 + reg >= nrows) { acc[m][0][reg] = -INFINITY; acc[m][1][reg] = -INFINITY; }
+        }
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            float mx = -INFINITY;
+            float gm[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) mx = fmaxf(mx, fmaxf(fmaxf(acc[m][n][0], acc[m][n][1]), fmaxf(acc[m][n][2], acc[m][n][3])));
-            if (mx > top[n].s[TK - 1]) {
+            for (int m = 0; m < 4; ++m) gm[m] = fmaxf(fmaxf(acc[m][n][0], acc[m][n][1]), fmaxf(acc[m][n][2], acc[m][n][3]));
+            const float mx = fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3]));
+            if (mx > top[n].s[TK - 1]) {                             // rare once the lists have warmed up
+                const int g0 = (int)((r0 + rbase) >> 2);             // r0 and rbase are multiples of 4
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int row = rbase + m * 16 + reg;
-                        if (row < nrows) topk_insert<TK>(top[n], acc[m][n][reg], (int)(r0 + row));
-                    }
+                for (int m = 0; m < 4; ++m) topk_insert<TK>(top[n], gm[m], g0 + m * 4);
             }
         }
     }
@@ -241,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void gallery_gemm_scan(ScanP p) {
 template <int K>
 __global__ __launch_bounds__(64) void gallery_rerank(const float* __restrict__ Q, const float* __restrict__ G32,
                                                      const float* __restrict__ ws_score, const int* __restrict__ ws_idx,
-                                                     int F, int ncand, int64_t row_offset, float coarse_unscale,
+                                                     int F, int64_t N, int ncand, int64_t row_offset, float coarse_unscale,
                                                      int64_t* __restrict__ out_idx, float* __restrict__ out_score,
                                                      const int32_t* __restrict__ seg_counts, int seg_len) {
     const int q = blockIdx.x, lane = threadIdx.x;
@@ -249,44 +271,71 @@ __global__ __launch_bounds__(64) void gallery_rerank(const float* __restrict__ Q
         if (lane == 0) { out_idx[q] = -1; out_score[q] = -1.0f; }
         return;
     }
+    // ONE pass over the candidates: every lane keeps the best K of its strided share (order: coarse score, then lowest
+    // group id), then K rounds of wave-wide argmax over the lanes' list heads pop the overall best K.
+    TopK<K> loc;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { loc.s[k] = -INFINITY; loc.i[k] = 0x7fffffff; }
+    for (int c = lane; c < ncand; c += 64) {
+        const float s = ws_score[(int64_t)q * ncand + c];
+        const int i = ws_idx[(int64_t)q * ncand + c];
+        if (i < 0 || !(s > loc.s[K - 1] || (s == loc.s[K - 1] && i < loc.i[K - 1]))) continue;
+        loc.s[K - 1] = s; loc.i[K - 1] = i;
+#pragma unroll
+        for (int k = K - 1; k > 0; --k) {
+            const bool up = loc.s[k] > loc.s[k - 1] || (loc.s[k] == loc.s[k - 1] && loc.i[k] < loc.i[k - 1]);
+            const float hs = up ? loc.s[k] : loc.s[k - 1], ls = up ? loc.s[k - 1] : loc.s[k];
+            const int hi = up ? loc.i[k] : loc.i[k - 1], li = up ? loc.i[k - 1] : loc.i[k];
+            loc.s[k - 1] = hs; loc.s[k] = ls; loc.i[k - 1] = hi; loc.i[k] = li;
+        }
+    }
     float bs[K]; int bi[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) { bs[k] = -INFINITY; bi[k] = -1; }
-    // K rounds of wave-wide argmax over the candidates (ties -> lowest row), removing the winner each time
     for (int round = 0; round < K; ++round) {
-        float ms = -INFINITY; int mi = 0x7fffffff;
-        for (int c = lane; c < ncand; c += 64) {
-            const float s = ws_score[(int64_t)q * ncand + c];
-            const int i = ws_idx[(int64_t)q * ncand + c];
-            bool taken = i < 0;
-#pragma unroll
-            for (int k = 0; k < K; ++k) taken |= (k < round && bi[k] == i);
-            if (!taken && (s > ms || (s == ms && i < mi))) { ms = s; mi = i; }
-        }
+        float ms = loc.s[0]; int mi = loc.i[0];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float os = __shfl_xor(ms, o, 64); const int oi = __shfl_xor(mi, o, 64);
             if (os > ms || (os == ms && oi < mi)) { ms = os; mi = oi; }
         }
+        bs[round] = ms; bi[round] = (mi == 0x7fffffff) ? -1 : mi;
+        if (mi != 0x7fffffff && loc.i[0] == mi) {                  // group ids are unique: exactly one lane pops
 #pragma unroll
-        for (int k = 0; k < K; ++k) if (k == round) { bs[k] = ms; bi[k] = (mi == 0x7fffffff) ? -1 : mi; }
+            for (int k = 0; k + 1 < K; ++k) { loc.s[k] = loc.s[k + 1]; loc.i[k] = loc.i[k + 1]; }
+            loc.s[K - 1] = -INFINITY; loc.i[K - 1] = 0x7fffffff;
+        }
     }
+    // bi[k] = group id (4 consecutive rows); re-score the rows of the K groups: 16 lanes per row, 4 rows per group
     float best = -INFINITY; int besti = -1;
+    const int sub = lane >> 4, l16 = lane & 15;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         if (bi[k] < 0) continue;
-        float s = bs[k] * coarse_unscale;
-        if (G32) {                                                 // exact f32 dot
-            const float* gg = G32 + (int64_t)bi[k] * GD;
+        const int64_t row = (int64_t)bi[k] * 4 + sub;
+        float s = bs[k] * coarse_unscale;                          // G32 == NULL: the group's coarse maximum stands for its rows
+        const bool ok = row < N;
+        if (G32) {                                                 // exact f32 dot, one row per 16 lanes
+            const float* gg = G32 + (ok ? row : 0) * GD;
             const float* qq = Q + (int64_t)q * GD;
             float pp = 0.f;
-            for (int c = lane * 4; c < GD; c += 256) {
-                const float4 a = *reinterpret_cast<const float4*>(qq + c), bb = *reinterpret_cast<const float4*>(gg + c);
+#pragma unroll
+            for (int c = 0; c < GD / 64; ++c) {
+                const float4 a = *reinterpret_cast<const float4*>(qq + c * 64 + l16 * 4);
+                const float4 bb = *reinterpret_cast<const float4*>(gg + c * 64 + l16 * 4);
                 pp += a.x * bb.x + a.y * bb.y + a.z * bb.z + a.w * bb.w;
             }
-            s = wave_sum(pp);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) pp += __shfl_xor(pp, o, 64);
+            s = pp;
         }
-        if (s > best || (s == best && bi[k] < besti)) { best = s; besti = bi[k]; }
+        float cs = ok ? s : -INFINITY;
+        int ci = ok ? (int)row : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o >= 16; o >>= 1) {                       // best of the group's 4 rows (lowest row on ties)
+            const float os = __shfl_xor(cs, o, 64); const int oi = __shfl_xor(ci, o, 64);
+            if (os > cs || (os == cs && oi < ci)) { cs = os; ci = oi; }
+        }
+        if (ci != 0x7fffffff && (cs > best || (cs == best && ci < besti) || besti < 0)) { best = cs; besti = ci; }
     }
     if (lane == 0) {
         if (besti < 0 || !(best > -1.0f)) { out_idx[q] = -1; out_score[q] = -1.0f; }
@@ -348,6 +397,7 @@ static int gemm_scan_launch(const char* who, const float* Q, const void* Gc, con
         ScanP p;
         p.Q = Q; p.G = Gc; p.F = F; p.N = N; p.nqt = pl.nqt; p.nranges = pl.nranges; p.rows_per_range = pl.rows_per_range;
         p.ws_score = ws_score; p.ws_idx = ws_idx; p.seg_counts = seg_counts; p.seg_len = seg_len; p.qscale = qscale;
+        p.abl = fr_dbg_int("FR_SCAN_ABL", 0);
         constexpr int lds = 2 * SG_ROWS * (FP8 ? 512 : 1024);
         static FrDevLatch latch;
         if (!fr_raise_lds(reinterpret_cast<const void*>(gallery_gemm_scan<FP8, TK>), lds, latch)) {
@@ -362,7 +412,7 @@ static int gemm_scan_launch(const char* who, const float* Q, const void* Gc, con
             return FR_E_LAUNCH;
         }
     }
-    gallery_rerank<TK><<<F, 64, 0, s>>>(Q, G32, ws_score, ws_idx, F, ncand, row_offset, coarse_unscale, out_idx, out_score,
+    gallery_rerank<TK><<<F, 64, 0, s>>>(Q, G32, ws_score, ws_idx, F, N, ncand, row_offset, coarse_unscale, out_idx, out_score,
                                         seg_counts, seg_len);
     FR_CHECK_LAUNCH("gallery_rerank");
     return FR_OK;
