@@ -24,6 +24,13 @@ class ConvArgs(C.Structure):
                 ("Ho", C.c_int), ("Wo", C.c_int), ("bias_mode", C.c_int), ("splitk", C.c_int)]
 
 
+class ConvF8Args(C.Structure):
+    _fields_ = [("x8", C.c_void_p), ("w8", C.c_void_p), ("y16", C.c_void_p), ("y8", C.c_void_p),
+                ("oscale", C.c_void_p), ("bias", C.c_void_p), ("slope", C.c_void_p), ("residual", C.c_void_p),
+                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
+                ("bias_mode", C.c_int), ("y8_mul", C.c_float)]
+
+
 _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
 # name -> (restype, argtypes); every symbol include/frhip.h declares
@@ -49,6 +56,8 @@ SIGNATURES = {
     "fr_cosine_matrix_f32": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "fr_mean_rows_f32": (_I, [_P, _I, _I, _P, _P]),
     "fr_conv_nhwc_f16": (_I, [C.POINTER(ConvArgs), _P]),
+    "fr_conv_nhwc_f8": (_I, [C.POINTER(ConvF8Args), _P]),
+    "fr_quantize_f16_f8": (_I, [_P, _P, _L, _F, _P]),
     "fr_conv_splitk_epilogue": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
     "fr_fc_reduce_l2norm": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
     "fr_warp_affine_5pt": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P]),

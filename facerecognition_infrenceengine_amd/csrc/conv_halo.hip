@@ -19,8 +19,9 @@
 #include <type_traits>
 
 struct HaloP {
-    const half_t* x; const half_t* w; half_t* y;
+    const half_t* x; const half_t* w; half_t* y;     // F8 variant: x, w are fp8 e4m3 bytes; y (f16) may be NULL
     const float* bias; const float* slope; const half_t* res;
+    const float* oscale; unsigned char* y8; float y8_mul;   // F8: acc * oscale[cout] first; optional fp8 copy of the output * y8_mul
     int B, H, W, Cin, Cout, bias_mode;
     int TH, tiles_per_img;      // output rows per tile, H / TH
     unsigned xbytes, wbytes;
@@ -28,6 +29,17 @@ struct HaloP {
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef int int8v __attribute__((ext_vector_type(8)));
+
+// 4 floats -> 4 fp8 e4m3 (OCP) bytes, saturating at +-448 (the conversion itself would produce NaN past the range)
+__device__ __forceinline__ int pack_fp8x4(float a, float b, float c, float d) {
+    a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+    c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+    int v = 0;
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return v;
+}
 
 #define HK 64          // channels per chunk
 
@@ -59,9 +71,17 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // block (first loads, epilogue: ~30 % of a 28x28 tile) and its barrier stalls are covered by the neighbour.
 // NA: 16-cout MFMA tiles per wave (4 = 64 couts).  (A 32-cout / 2-pixel-group split was tried for balance: it spilled at
 // 128 VGPRs and was replaced by SPLIT below.)
-template <int WN, int NPT, int XROWS, int NXBUF, int MINW, bool STAMPS, bool LEAN = false, int NA = 4>
+// F8: fp8 e4m3 activations and weights on v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales; twice the f16 MFMA
+// rate).  A chunk is 128 CHANNELS (still 128 B per LDS row), a K step is one tap x 128 channels = ONE MFMA per tile
+// pair, fed by the same two ds_read_b128 per operand as the f16 step's two K = 32 MFMAs (lane quarter fq holds bytes
+// [16 fq, +16) and [64 + 16 fq, +16) of the row: the k order inside an MFMA is free as long as A and B agree), so the
+// LDS image, swizzle, DMA pattern and barrier structure are the f16 kernel's; the K loop has half as many steps.
+template <int WN, int NPT, int XROWS, int NXBUF, int MINW, bool STAMPS, bool LEAN = false, int NA = 4, bool F8 = false>
 __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(!F8 || LEAN, "the fp8 variant exists for the lean schedule only");
+    constexpr int ES = F8 ? 1 : 2;                     // bytes per element
+    constexpr int CH = 128 / ES;                       // channels per 128-B chunk
     constexpr int BN = 16 * NA * WN;
     constexpr int WP = 8 / WN;
     // SPLIT (lean 196-pixel tiles): 13 pixel tiles over 4 pixel groups used to be 4+4+4+(1 real + 3 padding) tiles,
@@ -110,12 +130,12 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
         const int iy = y0 - 1 + hy, ix = hx - 1;
         const bool ok = h < nhalo && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         const int xch = (lane & 7) ^ ((h - 2 * hy) & 7);
-        xoff[i] = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.Cin + xch * 8) * 2) : 0x80000000u;
+        xoff[i] = ok ? (unsigned)(((n * p.H + iy) * p.W + ix) * p.Cin * ES + xch * 16) : 0x80000000u;
     }
     unsigned woff[NWI];
     const int K = 9 * p.Cin;
 #pragma unroll
-    for (int i = 0; i < NWI; ++i) woff[i] = (unsigned)(((cout0 + (wave * NWI + i) * 8 + lrow) * K + schunk * 8) * 2);
+    for (int i = 0; i < NWI; ++i) woff[i] = (unsigned)((cout0 + (wave * NWI + i) * 8 + lrow) * K * ES + schunk * 16);
 
     auto issue_x = [&](int c) {
         half_t* dst = xs + (c & (NXBUF - 1)) * XROWS * HK;
@@ -128,7 +148,7 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
     int wq_tap = 0, wq_c = 0;
     auto issue_w = [&](int q) {
         half_t* dst = ws + (q & 1) * BN * HK;
-        const int soff = (wq_tap * p.Cin + wq_c * HK) * 2;
+        const int soff = (wq_tap * p.Cin + wq_c * CH) * ES;
 #pragma unroll
         for (int i = 0; i < NWI; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(dst + (wave * NWI + i) * 8 * HK), 16, woff[i], soff, 0, 0);
@@ -169,7 +189,7 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
 #pragma unroll
         for (int j = 0; j < PT; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
 
-    const int nq = 9 * (p.Cin / HK), nchunk = p.Cin / HK;
+    const int nq = 9 * (p.Cin / CH), nchunk = p.Cin / CH;
     // fragment sets: (a0,b0) = K half 0 of the current step, (a1,b1) = K half 1.  Software pipeline:
     //   top:  read (a1,b1)(q)            | MFMA half 0 (q)      <- LDS reads fly under the MFMAs
     //   mid:  lgkmcnt(0), counted vmcnt, barrier: W(q+1) landed, W(q)'s buffer free
@@ -209,12 +229,85 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a[i]), __builtin_bit_cast(half8, b[j]),
                                                                    acc[i][j], 0, 0, 0);
     };
+    auto mfma8 = [&](const int4v& alo, const int4v& ahi, const int4v& blo, const int4v& bhi, float4v c) {
+        const int8v a = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+        const int8v b = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+        return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    };
 #pragma unroll
     for (int i = 0; i < NA; ++i) a0[i] = a1[i] = int4v{0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < PT; ++j) b0[j] = b1[j] = int4v{0, 0, 0, 0};
 
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, s01 = 0, s12 = 0, s23 = 0, s34 = 0, s45 = 0;
+    if constexpr (F8) {
+        // fp8 schedule: chunk loop x 9-tap inner loop; the tap step is ONE basic block (the weight DMA of the next step
+        // is issued unconditionally - the step after the last reads rows that are never consumed and is drained before
+        // the epilogue), so that the sched_group_barrier pipeline below can order reads against MFMAs.
+        issue_x(0);
+        issue_w(0);
+        int qq = 0;
+#pragma unroll 1
+        for (int c = 0; c < nchunk; ++c) {
+            int toff = 0, kw = 0, kh = 0;
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap, ++qq) {
+                const int q = qq;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // W(q) (and the halo issued at the last chunk end)
+                __builtin_amdgcn_s_barrier();
+                issue_w(q + 1);
+                // an 8-VGPR operand per tile: keep the pixel fragments (B) of the step live and stream the weight
+                    // fragments (A) one cout tile at a time, so that the kernel stays within 128 VGPRs (two blocks per CU)
+                    {
+                        const char* xl = reinterpret_cast<const char*>(xs) + toff * (HK * 2);
+                        const int ks = toff - 2 * kh;
+#pragma unroll
+                        for (int j = 0; j < PT; ++j) {
+                            const int key = (kbs[j] + ks) & 7;
+                            b0[j] = *reinterpret_cast<const int4v*>(xl + hoff[j] + ((fq ^ key) << 4));
+                            b1[j] = *reinterpret_cast<const int4v*>(xl + hoff[j] + (((4 + fq) ^ key) << 4));
+                        }
+                    }
+                    const half_t* wl = ws + (q & 1) * BN * HK + (wn * NA * 16) * HK;
+                    const int alo_off = fr * HK + ((fq ^ (fr & 7)) << 3), ahi_off = fr * HK + (((4 + fq) ^ (fr & 7)) << 3);
+                    int4v alo = *reinterpret_cast<const int4v*>(wl + alo_off), ahi = *reinterpret_cast<const int4v*>(wl + ahi_off);
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) {
+                        int4v nlo = alo, nhi = ahi;
+                        if (i + 1 < NA) {                           // next cout tile's fragment flies under this tile's MFMAs
+                            nlo = *reinterpret_cast<const int4v*>(wl + (i + 1) * 16 * HK + alo_off);
+                            nhi = *reinterpret_cast<const int4v*>(wl + (i + 1) * 16 * HK + ahi_off);
+                        }
+#pragma unroll
+                        for (int j = 0; j < PT; ++j) acc[i][j] = mfma8(alo, ahi, b0[j], b1[j], acc[i][j]);
+                        alo = nlo; ahi = nhi;
+                    }
+                    if constexpr (SPLIT) {
+                        read_x(ax0, bx0, q, c, toff, kh, 0); read_x(ax1, bx1, q, c, toff, kh, 1);
+                        accx = mfma8(ax0, ax1, bx0, bx1, accx);
+                    }
+                    // pin the order above (hipcc otherwise hoists all 18 fragment reads = 72 VGPRs to the top of the step
+                    // and spills): B + first A fragment, then per cout tile 3 MFMAs with the next tile's 2 reads between them
+#define FR_SGB_READ() do { __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } while (0)
+#define FR_SGB_MFMA() __builtin_amdgcn_sched_group_barrier(0x008, 1, 0)
+                    static_assert(!F8 || (PT == 3 && NA == 4 && SPLIT), "the fp8 schedule is written for the 4 x 3 + 1 tile split");
+#pragma unroll
+                    for (int g_ = 0; g_ < 2 * PT + 2; ++g_) FR_SGB_READ();
+#pragma unroll
+                    for (int i = 0; i < NA - 1; ++i) { FR_SGB_MFMA(); FR_SGB_READ(); FR_SGB_MFMA(); FR_SGB_READ(); FR_SGB_MFMA(); }
+                    FR_SGB_MFMA(); FR_SGB_READ(); FR_SGB_MFMA(); FR_SGB_READ(); FR_SGB_MFMA(); FR_SGB_READ(); FR_SGB_READ(); FR_SGB_MFMA();
+
+                ++kw; ++toff;
+                if (kw == 3) { kw = 0; toff += HW - 3; ++kh; }
+            }
+            if (c + 1 < nchunk) {                                    // reload the single halo buffer
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                        // every wave is done reading chunk c
+                issue_x(c + 1);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the surplus weight DMA must not land in the epilogue tile
+    } else
     if constexpr (LEAN) {
         static_assert(!LEAN || NXBUF == 1, "lean variant keeps one halo buffer");
         STAMP(tB);
@@ -357,6 +450,7 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
     };
     auto finish = [&](float4v v, int px, int col, int bsel) {       // bias -> PReLU -> + residual -> f16, in place in LDS
         const int co = cout0 + col;
+        if constexpr (F8) v *= *reinterpret_cast<const float4v*>(p.oscale + co);     // dequantise: sw[cout] * sx
         if (p.bias) v += *reinterpret_cast<const float4v*>(p.bias + bsel + co);
         if (p.slope) {
             const float4v sv = *reinterpret_cast<const float4v*>(p.slope + co);
@@ -384,10 +478,24 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
         if (px < npx) finish(accx, px, wn * NA * 16 + wp * 16 + fq * 4, bias_sel(px));
     }
     __syncthreads();
-    for (int e = tid; e < npx * CPR; e += 512) {
-        const int px = e / CPR, cc = e - px * CPR;
-        const int4v v = *reinterpret_cast<const int4v*>(ot + px * OP + cc * 8);
-        *reinterpret_cast<int4v*>(p.y + (size_t)(m_base + px) * p.Cout + cout0 + cc * 8) = v;
+    if (!F8 || p.y) {
+        for (int e = tid; e < npx * CPR; e += 512) {
+            const int px = e / CPR, cc = e - px * CPR;
+            const int4v v = *reinterpret_cast<const int4v*>(ot + px * OP + cc * 8);
+            *reinterpret_cast<int4v*>(p.y + (size_t)(m_base + px) * p.Cout + cout0 + cc * 8) = v;
+        }
+    }
+    if constexpr (F8) {
+        if (p.y8) {                                    // fp8 copy for the next conv: 8 channels = 8 bytes per thread
+            for (int e = tid; e < npx * CPR; e += 512) {
+                const int px = e / CPR, cc = e - px * CPR;
+                const half8 h = *reinterpret_cast<const half8*>(ot + px * OP + cc * 8);
+                int2 o;
+                o.x = pack_fp8x4((float)h[0] * p.y8_mul, (float)h[1] * p.y8_mul, (float)h[2] * p.y8_mul, (float)h[3] * p.y8_mul);
+                o.y = pack_fp8x4((float)h[4] * p.y8_mul, (float)h[5] * p.y8_mul, (float)h[6] * p.y8_mul, (float)h[7] * p.y8_mul);
+                *reinterpret_cast<int2*>(p.y8 + (size_t)(m_base + px) * p.Cout + cout0 + cc * 8) = o;
+            }
+        }
     }
     if (STAMPS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(tD);
@@ -399,7 +507,7 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
 #endif
 }
 
-template <int WN, int NPT, int XROWS, int NXBUF, int MINW, bool LEAN = false, int NA = 4>
+template <int WN, int NPT, int XROWS, int NXBUF, int MINW, bool LEAN = false, int NA = 4, bool F8 = false>
 static int launch_halo(const HaloP& p, hipStream_t s) {
     constexpr int BN = 16 * NA * WN;
     constexpr size_t opnd = (size_t)(NXBUF * XROWS * HK + 2 * BN * HK) * sizeof(half_t);
@@ -409,14 +517,14 @@ static int launch_halo(const HaloP& p, hipStream_t s) {
     if constexpr (FR_DEBUG) {                  // stamped twin: debug build only
         if (p.stamps) {
             static FrDevLatch dl;
-            auto dk = conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, true, LEAN, NA>;
+            auto dk = conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, true, LEAN, NA, F8>;
             if (!fr_raise_lds(reinterpret_cast<const void*>(dk), lds, dl)) { fr_set_error("conv_halo: cannot raise dynamic LDS"); return FR_E_LAUNCH; }
             dk<<<blocks, 512, lds, s>>>(p);
             return FR_OK;
         }
     }
     static FrDevLatch latch;
-    auto kern = conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, false, LEAN, NA>;
+    auto kern = conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, false, LEAN, NA, F8>;
     if (!fr_raise_lds(reinterpret_cast<const void*>(kern), lds, latch)) {
         fr_set_error("conv_halo: cannot raise dynamic LDS to %zu bytes", lds);
         return FR_E_LAUNCH;
@@ -440,6 +548,7 @@ int fr_conv_halo_try(const fr_conv_args* a, hipStream_t s) {
     HaloP p;
     p.x = (const half_t*)a->x; p.w = (const half_t*)a->w; p.y = (half_t*)a->y;
     p.bias = a->bias; p.slope = a->slope; p.res = (const half_t*)a->residual;
+    p.oscale = nullptr; p.y8 = nullptr; p.y8_mul = 0.f;
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.bias_mode = a->bias_mode;
     p.TH = TH; p.tiles_per_img = a->H / TH;
     p.xbytes = (unsigned)((int64_t)a->B * a->H * a->W * a->Cin * 2);
@@ -458,4 +567,50 @@ int fr_conv_halo_try(const fr_conv_args* a, hipStream_t s) {
         else rc = FR_E_INVALID;
     }
     return rc == FR_OK ? 1 : rc;
+}
+
+// ---------------------------------------------------------------- fp8 body convs (BASELINE config C5)
+extern "C" int fr_conv_nhwc_f8(const fr_conv_f8_args* a, fr_stream_t stream) {
+    FR_REQUIRE(a, "fr_conv_nhwc_f8: null args");
+    FR_REQUIRE(a->x8 && a->w8 && a->oscale && (a->y16 || a->y8), "fr_conv_nhwc_f8: null tensor");
+    FR_REQUIRE(a->B > 0 && a->H == a->W && (a->H == 14 || a->H == 28), "fr_conv_nhwc_f8: 3x3/s1/p1 layers at 14x14 or 28x28 only (got %dx%d)", a->H, a->W);
+    FR_REQUIRE(a->Cin % 128 == 0 && a->Cout % 128 == 0, "fr_conv_nhwc_f8: Cin and Cout must be multiples of 128 (got %d, %d)", a->Cin, a->Cout);
+    FR_REQUIRE(a->bias_mode == 0 || a->bias_mode == 1, "fr_conv_nhwc_f8: bad bias_mode");
+    FR_REQUIRE((int64_t)a->B * a->H * a->W * a->Cin < (1ll << 31) && (int64_t)a->Cout * 9 * a->Cin < (1ll << 31), "fr_conv_nhwc_f8: tensor too large");
+    HaloP p;
+    p.x = (const half_t*)a->x8; p.w = (const half_t*)a->w8; p.y = (half_t*)a->y16;
+    p.bias = a->bias; p.slope = a->slope; p.res = (const half_t*)a->residual;
+    p.oscale = a->oscale; p.y8 = (unsigned char*)a->y8; p.y8_mul = a->y8_mul;
+    p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.bias_mode = a->bias_mode;
+    p.TH = a->H == 14 ? 14 : 7; p.tiles_per_img = a->H / p.TH;
+    p.xbytes = (unsigned)((int64_t)a->B * a->H * a->W * a->Cin);
+    p.wbytes = (unsigned)((int64_t)a->Cout * 9 * a->Cin);
+    p.stamps = (unsigned long long*)fr_dbg_ptr("FR_DBG_STAMPS");
+    hipStream_t s = fr_stream(stream);
+    const int rc = a->H == 28 ? launch_halo<2, 13, 320, 1, 4, true, 4, true>(p, s) : launch_halo<2, 13, 256, 1, 4, true, 4, true>(p, s);
+    if (rc != FR_OK) return rc;
+    FR_CHECK_LAUNCH("conv_halo_f8");
+    return FR_OK;
+}
+
+// f16 -> fp8 e4m3 (x * mul, saturating): input of the first fp8 conv of a stage
+__global__ void quantize_f16_f8(const half_t* __restrict__ x, unsigned char* __restrict__ out, int64_t n8, float mul) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const half8 h = *reinterpret_cast<const half8*>(x + i * 8);
+        int2 o;
+        o.x = pack_fp8x4((float)h[0] * mul, (float)h[1] * mul, (float)h[2] * mul, (float)h[3] * mul);
+        o.y = pack_fp8x4((float)h[4] * mul, (float)h[5] * mul, (float)h[6] * mul, (float)h[7] * mul);
+        *reinterpret_cast<int2*>(out + i * 8) = o;
+    }
+}
+
+extern "C" int fr_quantize_f16_f8(const void* x16, void* out8, int64_t n, float mul, fr_stream_t stream) {
+    if (n <= 0) return FR_OK;
+    FR_REQUIRE(x16 && out8 && n % 8 == 0, "fr_quantize_f16_f8: null pointer or n not a multiple of 8");
+    int64_t blocks = (n / 8 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    quantize_f16_f8<<<(int)blocks, 256, 0, fr_stream(stream)>>>((const half_t*)x16, (unsigned char*)out8, n / 8, mul);
+    FR_CHECK_LAUNCH("quantize_f16_f8");
+    return FR_OK;
 }

@@ -40,11 +40,31 @@ def _pack_w(w):
     return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(torch.float16).contiguous()
 
 
+F8_MAX = 448.0                 # largest finite OCP e4m3 value
+F8_MARGIN = 1.5                # activation scale head-room over the calibration batch's absmax
+
+
+def f8_eligible(c, H):
+    """Layers fr_conv_nhwc_f8 takes: 3x3 / stride 1 at 28x28 and 14x14 with 128-multiple channels (78 % of r100)."""
+    return c.k == 3 and c.stride == 1 and H in (14, 28) and c.cin % 128 == 0 and c.cout % 128 == 0
+
+
+def quantise_weights_f8(w):
+    """[Cout, K] (f64/f32, folded) -> (uint8 e4m3 bytes [Cout, K], per-output-channel scale sw f32 [Cout]):
+    w8 = fp8(w / sw), sw = max|w[co]| / 448."""
+    w = w.to(torch.float32)
+    sw = (w.abs().amax(dim=1) / F8_MAX).clamp_min(1e-30)
+    q = (w / sw[:, None]).clamp(-F8_MAX, F8_MAX).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).contiguous(), sw
+
+
 class _Conv:
-    __slots__ = ("w", "bias", "slope", "cin", "cout", "k", "stride", "pad", "bias_mode")
+    __slots__ = ("w", "bias", "slope", "cin", "cout", "k", "stride", "pad", "bias_mode", "w32", "w8", "sw", "sx",
+                 "oscale")
 
     def __init__(self, w, bias, slope, cin, cout, k, stride, pad, bias_mode, device):
         self.w = w.to(device)
+        self.w32 = self.w8 = self.sw = self.sx = self.oscale = None      # fp8 form, filled by IResNetHIP.enable_fp8
         self.bias = None if bias is None else bias.to(torch.float32).contiguous().to(device)
         self.slope = None if slope is None else slope.to(torch.float32).contiguous().to(device)
         self.cin, self.cout, self.k, self.stride, self.pad, self.bias_mode = cin, cout, k, stride, pad, bias_mode
@@ -90,6 +110,10 @@ class IResNetHIP:
                 c1 = _Conv(_pack_w(w1f), bias9.reshape(9 * cout), st[p + ".prelu.weight"], cin, cout, 3, 1, 1, 1, dev)
                 w2f = st[p + ".conv2.weight"].double() * s3[:, None, None, None]
                 c2 = _Conv(_pack_w(w2f), t3, None, cout, cout, 3, stride, 1, 0, dev)
+                if cin % 128 == 0 and cout % 128 == 0:        # folded f32 weights kept on the host for enable_fp8()
+                    c1.w32 = w1f.permute(0, 2, 3, 1).reshape(cout, -1).to(torch.float32)
+                if stride == 1 and cout % 128 == 0:
+                    c2.w32 = w2f.permute(0, 2, 3, 1).reshape(cout, -1).to(torch.float32)
                 sc = None
                 if bi == 0:
                     sd, td = _bn_fold(st, p + ".downsample.1")
@@ -107,6 +131,54 @@ class IResNetHIP:
         self.fc_bias = bias.to(torch.float32).contiguous().to(dev)
         self.flops_per_face = self._count_flops()
         self.profile = None          # bench.py: list collecting (kernel variant, flops, ev0, ev1) per conv launch
+        self.fp8 = False             # enable_fp8(): eligible body convs run on the fp8 matrix cores
+        self._calib = None
+
+    # ---- fp8 path (BASELINE config C5)
+    def enable_fp8(self, calib_crops):
+        """Switch the eligible 3x3/s1 body convs (28x28, 14x14; 78 % of the r100 FLOPs) to fr_conv_nhwc_f8.
+        Weights: per-output-channel e4m3 (w / sw[co]).  Activations: per-tensor static scales from ONE f16 forward of
+        ``calib_crops`` (f16 [B,112,112,8], as produced by fr_warp_affine_5pt): sx = 1.5 * absmax / 448.  The
+        residual stream, stem, stride-2 convs, 1x1 shortcuts, the 7x7 stage and the FC stay f16."""
+        assert calib_crops.dtype == torch.float16 and calib_crops.shape[1:] == (112, 112, 8)
+        self.fp8 = False
+        self._calib = {}
+        self.forward(calib_crops.contiguous())
+        calib, self._calib = self._calib, None
+        n = 0
+        for c1, c2, _ in self.blocks:
+            for c in (c1, c2):
+                if id(c) in calib and c.w32 is not None:
+                    c.sx = max(calib[id(c)] * F8_MARGIN / F8_MAX, 1e-12)
+                    if c.w8 is None:
+                        w8, sw = quantise_weights_f8(c.w32)
+                        c.w8, c.sw = w8.to(self.device), sw.to(self.device)
+                    c.oscale = (c.sw * c.sx).contiguous()
+                    n += 1
+        self.fp8 = n > 0
+        return n
+
+    def _conv_f8(self, x8, c, B, H, W, residual=None, want16=True, y8_mul=None):
+        y16 = torch.empty((B, H, W, c.cout), dtype=torch.float16, device=self.device) if want16 else None
+        y8 = torch.empty((B, H, W, c.cout), dtype=torch.uint8, device=self.device) if y8_mul is not None else None
+        a = _lib.ConvF8Args(_lib.ptr(x8), _lib.ptr(c.w8), _lib.ptr(y16), _lib.ptr(y8), _lib.ptr(c.oscale),
+                            _lib.ptr(c.bias), _lib.ptr(c.slope), _lib.ptr(residual), B, H, W, c.cin, c.cout,
+                            c.bias_mode, float(y8_mul or 0.0))
+        if self.profile is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.lib.fr_conv_nhwc_f8(ctypes.byref(a), _lib.stream_ptr())
+            e1.record()
+            self.profile.append(("conv_halo_kernel<2, 13, %d, 1, 4, false, true, 4, true>" % (256 if H == 14 else 320),
+                                 2.0 * B * H * W * c.cout * 9 * c.cin, e0, e1))
+        else:
+            self.lib.fr_conv_nhwc_f8(ctypes.byref(a), _lib.stream_ptr())
+        return y16, y8
+
+    def _quantise(self, x16, mul):
+        out = torch.empty(x16.shape, dtype=torch.uint8, device=self.device)
+        self.lib.fr_quantize_f16_f8(_lib.ptr(x16), _lib.ptr(out), x16.numel(), float(mul), _lib.stream_ptr())
+        return out
 
     def _count_flops(self):
         f, hw = 2 * 112 * 112 * 27 * 64, 112
@@ -190,8 +262,22 @@ class IResNetHIP:
         if taps is not None:
             taps["stem"] = h
         li = 0
-        for c1, c2, sc in self.blocks:
-            mid, _, _ = self._conv(h, c1, B, H, W)
+        h8 = None                                  # fp8 copy of h, scaled for the conv that will read it (or None)
+        nb = len(self.blocks)
+        for bi_, (c1, c2, sc) in enumerate(self.blocks):
+            if self._calib is not None:            # enable_fp8(): absmax of the tensors the eligible convs read
+                if f8_eligible(c1, H):
+                    self._calib[id(c1)] = max(self._calib.get(id(c1), 0.0), float(h.abs().max()))
+            f1 = self.fp8 and c1.oscale is not None and f8_eligible(c1, H)
+            f2 = self.fp8 and c2.oscale is not None and f8_eligible(c2, H)
+            mid8 = None
+            if f1:
+                if h8 is None:
+                    h8 = self._quantise(h, 1.0 / c1.sx)
+                mid, mid8 = self._conv_f8(h8, c1, B, H, W, want16=not f2 or taps is not None,
+                                          y8_mul=(1.0 / c2.sx) if f2 else None)
+            else:
+                mid, _, _ = self._conv(h, c1, B, H, W)
             if sc is not None:
                 li += 1
                 if taps is not None:
@@ -199,7 +285,18 @@ class IResNetHIP:
                 short, _, _ = self._conv(h, sc, B, H, W)
             else:
                 short = h
-            h, H, W = self._conv(mid, c2, B, H, W, residual=short)
+            if self._calib is not None and f8_eligible(c2, H):
+                self._calib[id(c2)] = max(self._calib.get(id(c2), 0.0), float(mid.abs().max()))
+            if f2:
+                if mid8 is None:
+                    mid8 = self._quantise(mid, 1.0 / c2.sx)
+                nxt = self.blocks[bi_ + 1][0] if bi_ + 1 < nb else None
+                nf1 = nxt is not None and nxt.oscale is not None and f8_eligible(nxt, H)
+                h, h8 = self._conv_f8(mid8, c2, B, H, W, residual=short, want16=True,
+                                      y8_mul=(1.0 / nxt.sx) if nf1 else None)
+            else:
+                h, H, W = self._conv(mid, c2, B, H, W, residual=short)
+                h8 = None
             if taps is not None:
                 taps[f"_block{len(taps)}"] = None
         if taps is not None:

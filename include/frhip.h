@@ -142,6 +142,22 @@ typedef struct {
     int bias_mode; int splitk;
 } fr_conv_args;
 int fr_conv_nhwc_f16(const fr_conv_args* args, fr_stream_t stream);
+/* fp8 form of the body convs (BASELINE config C5: "fp8 ArcFace conv path, CDNA4 fp8 MFMA"; same reference site,
+ * infrenceServer.py:528): 3x3 / stride 1 / pad 1 layers at 14x14 and 28x28 (78 % of the r100 FLOPs) on
+ * v_mfma_scale_f32_16x16x128_f8f6f4.  x8: OCP fp8 e4m3 NHWC [B,H,W,Cin] = x / sx; w8: e4m3 [Cout][9*Cin] =
+ * w / sw[cout] (per-output-channel); oscale[cout] = sw[cout] * sx dequantises the f32 accumulator, then the f16
+ * kernel's epilogue: + bias (or 9-class border bias) -> PReLU -> + residual (f16) -> one rounding.  Outputs:
+ * y16 (f16 NHWC, may be NULL) and/or y8 = fp8(y * y8_mul) (the next conv's input, may be NULL).
+ * Cin % 128 == 0, Cout % 128 == 0. */
+typedef struct {
+    const void* x8; const void* w8; void* y16; void* y8;
+    const float* oscale; const float* bias; const float* slope; const void* residual;
+    int B, H, W, Cin, Cout, bias_mode;
+    float y8_mul;
+} fr_conv_f8_args;
+int fr_conv_nhwc_f8(const fr_conv_f8_args* args, fr_stream_t stream);
+/* out8 = fp8_e4m3(x16 * mul), saturating at +-448; n % 8 == 0 (input of a stage's first fp8 conv) */
+int fr_quantize_f16_f8(const void* x16, void* out8, int64_t n, float mul, fr_stream_t stream);
 /* Split-K tail of an ordinary conv (small batches): y = epi(sum_z partial[z]) with the epilogue of fr_conv_nhwc_f16
  * (bias or 9-class border bias, PReLU, residual, one rounding to f16).  partial: f32 [splitk][M][Cout]. */
 int fr_conv_splitk_epilogue(const float* partial, int splitk, int M, int Cout, int Ho, int Wo,

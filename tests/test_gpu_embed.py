@@ -141,3 +141,133 @@ def test_r50_variant_vs_oracle():
     cos = (emb * ref).sum(1) / (np.linalg.norm(emb, axis=1) * np.linalg.norm(ref, axis=1))
     assert (1 - cos).max() < 1e-3, cos
     assert abs(net.flops_per_face / 1e9 - 12.6) < 0.2          # 12.62 GFLOP / face
+
+
+# ---------------------------------------------------------------- fp8 body convs (BASELINE config C5)
+def _f8(t):
+    """Round a float tensor to OCP e4m3 and back (values the kernel sees exactly)."""
+    return t.clamp(-448, 448).to(torch.float8_e4m3fn)
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, Cin, Cout, bias_mode, slope, residual, want16, want8
+    (2, 14, 256, 256, 1, True, False, False, True),      # stage-3 conv1: border bias + PReLU, fp8 output only
+    (2, 14, 256, 256, 0, False, True, True, True),       # stage-3 conv2: + residual, both outputs
+    (3, 28, 128, 128, 1, True, False, True, False),      # 28x28 (7-row tiles), f16 output only
+    (1, 28, 128, 256, 0, False, True, True, True),       # first block of stage 3: 128 -> 256
+    (5, 14, 256, 512, 1, True, False, True, False),      # first block of stage 4: 256 -> 512, odd batch
+])
+def test_conv_f8_layer_vs_torch(lib, case):
+    """fr_conv_nhwc_f8 against a float conv of the SAME fp8-rounded operands: with f32 accumulation the only
+    difference is summation order, so the tolerance is f32-tight; the f16 output adds one f16 rounding and the fp8
+    output one e4m3 rounding (compared after rounding the reference the same way, allowing 1 code of slack)."""
+    from facerecognition_infrenceengine_amd import _lib
+    B, H, Cin, Cout, bias_mode, slope, residual, want16, want8 = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    sx, y8_mul = 0.037, 3.1
+    x8 = _f8(torch.randn((B, H, H, Cin), generator=g) * 40)                       # NHWC codes
+    w = torch.randn((Cout, 9 * Cin), generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    sw = w.abs().amax(1) / 448
+    w8 = _f8(w / sw[:, None])
+    xf = x8.float() * sx
+    wf = (w8.float() * sw[:, None]).reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(xf.permute(0, 3, 1, 2).double(), wf.double(), None, 1, 1).float()
+    if bias_mode == 1:
+        b9 = torch.randn((3, 3, Cout), generator=g)
+        rc = torch.ones(H, dtype=torch.long); rc[0] = 0; rc[-1] = 2
+        ref = ref + b9[rc][:, rc].permute(2, 0, 1)[None]
+        bias = b9.reshape(-1)
+    else:
+        bias = torch.randn(Cout, generator=g)
+        ref = ref + bias[None, :, None, None]
+    sl = None
+    if slope:
+        sl = torch.rand(Cout, generator=g) * 0.5
+        ref = torch.where(ref > 0, ref, ref * sl[None, :, None, None])
+    res = None
+    if residual:
+        res = torch.randn((B, H, H, Cout), generator=g).to(torch.float16)
+        ref = ref + res.float().permute(0, 3, 1, 2)
+    ref = ref.permute(0, 2, 3, 1)                                                   # NHWC
+    y16 = torch.empty((B, H, H, Cout), dtype=torch.float16, device="cuda") if want16 else None
+    y8 = torch.empty((B, H, H, Cout), dtype=torch.uint8, device="cuda") if want8 else None
+    xd, wd = x8.view(torch.uint8).cuda(), w8.view(torch.uint8).cuda()
+    osc = (sw * sx).float().cuda()
+    bd = bias.cuda(); sd = sl.cuda() if sl is not None else None; rd = res.cuda() if res is not None else None
+    a = _lib.ConvF8Args(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y16), _lib.ptr(y8), _lib.ptr(osc), _lib.ptr(bd), _lib.ptr(sd),
+                        _lib.ptr(rd), B, H, H, Cin, Cout, bias_mode, y8_mul)
+    lib.fr_conv_nhwc_f8(ctypes.byref(a), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    if want16:
+        err = (y16.float().cpu() - ref).abs().max().item()
+        assert err <= 1.2e-3 * scale, (err, scale)                                  # one f16 rounding (2^-11 relative)
+    if want8:
+        got = y8.cpu().view(torch.float8_e4m3fn).float()
+        want = _f8(ref.to(torch.float16).float() * y8_mul).float()
+        # equal e4m3 codes except where the f16 value sat on a rounding boundary: allow one code step (12.5 %)
+        bad = (got - want).abs() > 0.13 * want.abs() + 1e-3
+        assert bad.float().mean().item() < 1e-3 and not torch.isnan(got).any()
+        assert (got != want).float().mean().item() < 0.02
+
+
+def test_quantize_f16_f8_matches_torch(lib):
+    from facerecognition_infrenceengine_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(4096 * 8, generator=g) * 100).to(torch.float16)
+    x[:4] = torch.tensor([1e4, -1e4, 0.0, 448.0], dtype=torch.float16)             # saturation, zero, the maximum
+    xd = x.cuda(); out = torch.empty(x.shape, dtype=torch.uint8, device="cuda")
+    lib.fr_quantize_f16_f8(_lib.ptr(xd), _lib.ptr(out), x.numel(), 0.5, _lib.stream_ptr())
+    got = out.cpu().view(torch.float8_e4m3fn).float()
+    want = _f8(x.float() * 0.5).float()
+    assert torch.equal(got, want)
+
+
+def test_r100_fp8_embedding_vs_golden(golden):
+    """The fp8 path against the fp32 oracle (r100_kat.npz): states the achieved 1 - cos.  north_star's 1e-3 bound is
+    an f16 statement; e4m3 carries 3 mantissa bits, so the fp8 bound asserted here is 1e-2 and the measured value
+    is printed (DESIGN.md quotes it).  Top-1 ids after the exact match are checked in test_fp8_ids_... below."""
+    from facerecognition_infrenceengine_amd import weights
+    from facerecognition_infrenceengine_amd.iresnet import IResNetHIP
+    net = IResNetHIP(weights.synth_iresnet_state("r100", seed=1234), "r100", "cuda:0")
+    d = golden("r100_kat.npz")
+    x = nchw_to_nhwc8(torch.from_numpy(d["x"]))
+    g = torch.Generator().manual_seed(11)
+    calib = nchw_to_nhwc8(torch.rand((16, 3, 112, 112), generator=g) * 2 - 1)
+    e16, _ = net.forward(x)
+    n = net.enable_fp8(calib)
+    assert n == 2 * 12 + 1 + 2 * 29 + 1                       # stage 2: 12 blocks, stage 3: 29 blocks, + 2 stage-entry conv1s
+    e8, n8 = net.forward(x)
+    ref = d["embedding"]
+    cos = lambda a, b: (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))   # noqa: E731
+    c8, c16 = cos(e8.cpu().numpy(), ref), cos(e16.cpu().numpy(), ref)
+    print(f"\\nfp8 r100: 1-cos vs fp32 oracle max {float((1 - c8).max()):.3e} (f16 path {float((1 - c16).max()):.3e})")
+    assert (1 - c8).max() < 1e-2, c8
+    np.testing.assert_allclose(np.linalg.norm(n8.cpu().numpy(), axis=1), 1.0, atol=1e-6)
+    assert not torch.isnan(e8).any()
+
+
+def test_fp8_ids_equal_oracle_ids_after_match():
+    """C5 end of the path: fp8 embeddings -> exact gallery match.  Gallery rows are the ORACLE's (fp32) embeddings of
+    64 faces plus 5 000 random rows; every fp8 query must match its own face's row, as the oracle query does."""
+    from facerecognition_infrenceengine_amd import weights
+    from facerecognition_infrenceengine_amd.gallery import GalleryMatcher
+    from facerecognition_infrenceengine_amd.iresnet import IResNetHIP
+    from oracle import match as omatch, nets as onets
+    st = weights.synth_iresnet_state("r50", seed=5)
+    net = IResNetHIP(st, "r50", "cuda:0")
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand((64, 3, 112, 112), generator=g) * 2 - 1
+    ref = onets.iresnet_forward(st, x, weights.IRESNET_LAYERS["r50"]).numpy()
+    assert net.enable_fp8(nchw_to_nhwc8(x[:16])) > 0
+    e8, n8 = net.forward(nchw_to_nhwc8(x))
+    rng = np.random.default_rng(2)
+    G = np.concatenate([rng.standard_normal((5000, 512)).astype(np.float32), ref])
+    G /= np.linalg.norm(G, axis=1, keepdims=True)
+    for scan in ("f32", "f8"):
+        m = GalleryMatcher("cuda:0", scan=scan)
+        m.set_rows(range(len(G)), G, normalise=False)
+        idx, score = m.match_device(n8)
+        oi, _ = omatch.match_rows_fast(ref / np.linalg.norm(ref, axis=1, keepdims=True), G)
+        assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(oi, 5000 + np.arange(64))
+        assert float(score.min()) > 0.9

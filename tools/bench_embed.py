@@ -1,23 +1,27 @@
-"""Dev tool: time the IResNet forward (and per-layer kernels) on the GPU."""
-import sys, os, time
+"""Dev tool: embed net alone (r100, 256 faces): ms per forward, f16 and fp8."""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from facerecognition_infrenceengine_amd import weights
 from facerecognition_infrenceengine_amd.iresnet import IResNetHIP
-
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-arch = sys.argv[2] if len(sys.argv) > 2 else "r100"
-net = IResNetHIP(weights.synth_iresnet_state(arch), arch)
-x = (torch.rand((B, 112, 112, 8), device="cuda") * 2 - 1).half()
-x[..., 3:] = 0
-for _ in range(3):
-    net.forward(x)
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-n = 10
-e0.record()
-for _ in range(n):
-    net.forward(x)
-e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / n
-print(f"{arch} B={B}: {ms:.3f} ms/forward, {B/ms*1e3:.0f} faces/s, {net.flops_per_face*B/ms/1e9:.1f} TFLOP/s")
+net = IResNetHIP(weights.synth_iresnet_state("r100"), "r100", "cuda:0")
+x = (torch.rand((B, 112, 112, 8), device="cuda") * 2 - 1).half(); x[..., 3:] = 0
+for mode in ("f16", "fp8"):
+    if mode == "fp8":
+        net.enable_fp8(x[:32].contiguous())
+    for _ in range(3): net.forward(x)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): net.forward(x)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    print(f"{mode}: {ms:.3f} ms / {B} faces = {B/ms*1e3:.0f} faces/s, {net.flops_per_face*B/ms/1e9:.0f} TFLOP/s", flush=True)
+    net.profile = []
+    net.forward(x); torch.cuda.synchronize()
+    per = {}
+    for v, fl, a, b in net.profile:
+        d = per.setdefault(v, [0, 0.0, 0.0]); d[0] += 1; d[1] += fl; d[2] += a.elapsed_time(b)
+    net.profile = None
+    for v, (n, fl, t) in sorted(per.items(), key=lambda kv: -kv[1][2]):
+        print(f"   {v:62s} x{n:3d} {t:7.3f} ms  {fl/t/1e9:7.0f} TFLOP/s")
