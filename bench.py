@@ -33,6 +33,7 @@ FRAMES, H, W = 64, 1080, 1920
 GALLERY_ROWS = 10_000
 FACES_PER_FRAME = 4                    # O-Net cap (C2 keeps F = 4 -> 256 faces/batch)
 MFMA_PEAK_TFLOPS = 2500.0              # dense f16/bf16 (MI355X_MICROARCH.md)
+MFMA_PEAK_TFLOPS_F8 = 5000.0           # dense fp8 (block-scaled MFMA with unit scales)
 PMC_FILE = "profiles/r02_pmc_traffic.json"
 
 
@@ -149,15 +150,20 @@ def main():
     ap.add_argument("--one-stream", action="store_true", help="detector and embedder on one stream (no overlap)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3"],
+    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C5"],
                     help="BASELINE.json config: C2 (default, the headline: 64x1080p, 4 faces/frame, 10k rows); C1 (1 x "
-                         "640x480, 1 face, 100 rows) and C3 (8 x 4K, 16 faces/frame) are side measurements for DESIGN.md")
+                         "640x480, 1 face, 100 rows), C3 (8 x 4K, 16 faces/frame) and C5 (fp8 embed convs + fp8 scan of "
+                         "a 10 M-row gallery row-sharded 8 ways: 1.25 M rows per GPU) are side measurements for DESIGN.md")
     args = ap.parse_args()
     global FRAMES, H, W, FACES_PER_FRAME, GALLERY_ROWS
     if args.workload == "C1":
         FRAMES, H, W, FACES_PER_FRAME, GALLERY_ROWS = 1, 480, 640, 1, 100
     elif args.workload == "C3":
         FRAMES, H, W, FACES_PER_FRAME = 8, 2160, 3840, 16
+    world_env = int(os.environ.get("WORLD_SIZE", str(max(args.gpus, 1))))
+    if args.workload == "C5":           # 10 M rows over 8 GPUs; fewer ranks keep the per-GPU shard (1.25 M rows)
+        GALLERY_ROWS = 1_250_000 * world_env
+        args.gallery = "f8"
     if args.gallery_rows:
         GALLERY_ROWS = args.gallery_rows
 
@@ -188,17 +194,25 @@ def main():
         app = FaceAnalysis(name="synthetic", arch="r100", cap_o=FACES_PER_FRAME)
         app.prepare(ctx_id=local_rank)
 
-    # gallery: seed-1 unit rows, row-sharded over the ranks
-    g = torch.Generator(device=device).manual_seed(1)
-    G = torch.randn((GALLERY_ROWS, 512), generator=g, device=device)
+    # gallery: seeded unit rows, row-sharded over the ranks
     lo, hi = shard_rows(GALLERY_ROWS, world, rank)
+    if GALLERY_ROWS > 2_000_000:            # large galleries: every rank draws only its own shard (seed = shard start)
+        g = torch.Generator(device=device).manual_seed(1 + lo)
+        Gs = torch.randn((hi - lo, 512), generator=g, device=device)
+    else:
+        g = torch.Generator(device=device).manual_seed(1)
+        Gs = torch.randn((GALLERY_ROWS, 512), generator=g, device=device)[lo:hi].contiguous()
     gm = GalleryMatcher(device, scan=args.gallery)
-    gm.set_rows(range(lo, hi), G[lo:hi].contiguous(), normalise=True)
+    gm.set_rows(range(lo, hi), Gs, normalise=True)
+    del Gs
     q_max = FRAMES * FACES_PER_FRAME
     sharded = ShardedGalleryMatcher(HipOps(gm, lo), q_max, force_exchange=args.force_exchange)
 
     nbatch = min(max(args.steps, 1), 3)
     batches = [synth_frames(FRAMES, H, W, rank * 1000 + i, device) for i in range(nbatch)]
+    if args.workload == "C5":               # fp8 body convs, calibrated on the faces of the first batch
+        n8 = app.calibrate_fp8(batches[0][:16])
+        assert n8 > 0
 
     ingest = None
     if args.ingest == "pinned":
@@ -363,8 +377,9 @@ def main():
             traffic = max(hits, key=lambda v: v.get("dispatches", 0))["hbm_bytes_per_launch_corrected"]
     except (OSError, KeyError, ValueError):
         pass
-    roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+    peak = MFMA_PEAK_TFLOPS_F8 if dom.endswith(", true>") and "conv_halo" in dom and dom.count(",") == 8 else MFMA_PEAK_TFLOPS
+    roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_source": f"{PMC_FILE}: rocprofv3 --pmc passes of tools/pmc_traffic.py (separate run; counters "
                                   "cannot be read from inside this process)" if traffic is not None else None,
                 "launches_per_step": calls, "avg_launch_us": round(secs / calls * 1e6, 2),
@@ -389,9 +404,9 @@ def main():
         out = {"metric": "faces/sec end-to-end @1080p" if args.workload == "C2" else f"faces/sec end-to-end @{H}p", "value": round(faces / dt, 1), "unit": "faces/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+               "vs_baseline": None, "dtype": "fp8" if args.workload == "C5" else "f16", "data": "synthetic",
                "config": {"workload": f"{args.workload}: {FRAMES}x{H}p synthetic frames/GPU, MTCNN full pyramid (caps "
-                                      f"512/64/{FACES_PER_FRAME}), ArcFace r100 f16 embed, {GALLERY_ROWS}-row cosine "
+                                      f"512/64/{FACES_PER_FRAME}), ArcFace r100 {'fp8 body convs' if args.workload == 'C5' else 'f16'} embed, {GALLERY_ROWS}-row cosine "
                                       "gallery (row-sharded over ranks)",
                           "frames_per_step_per_gpu": FRAMES, "ingest": args.ingest, "faces_per_step": faces / args.steps,
                           "gallery_rows": GALLERY_ROWS, "gallery_scan": args.gallery, "weights": "seeded synthetic",

