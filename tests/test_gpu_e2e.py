@@ -311,3 +311,55 @@ def test_processor_threads_share_one_engine_while_the_gallery_syncs(app):
     tc.start(); [t.start() for t in ts]; [t.join() for t in ts]
     stop.set(); tc.join()
     assert not errors and done == [12, 12, 12], (errors, done)
+
+
+def test_c2_geometry_1080p_frame_vs_oracle(app):
+    """BASELINE config C2's frame geometry (1080 x 1920: 12 pyramid levels) end to end against the CPU oracle:
+    detect -> align -> embed -> match of ONE full-HD frame through the reference-shaped get()."""
+    from facerecognition_infrenceengine_amd.gallery import GalleryMatcher
+    from facerecognition_infrenceengine_amd.mtcnn import pyramid_scales
+    from make_golden import synth_frame
+    assert len(pyramid_scales(1080, 1920)) == 12
+    frame = synth_frame(1080, 1920, 31)
+    ob, os_, ok, oemb = oracle_pipeline(frame)
+    faces = app.get(frame)
+    assert len(faces) == len(os_) >= 1
+    np.testing.assert_allclose(np.stack([f.bbox for f in faces]), ob, atol=1e-2)
+    np.testing.assert_allclose(np.array([f.det_score for f in faces]), os_, atol=5e-5)
+    np.testing.assert_allclose(np.stack([f.kps for f in faces]), ok, atol=1e-2)
+    emb = np.stack([f.embedding for f in faces])
+    cos = (emb * oemb).sum(1) / (np.linalg.norm(emb, axis=1) * np.linalg.norm(oemb, axis=1))
+    assert (1 - cos).max() < 1e-3, cos
+    rng = np.random.default_rng(8)
+    G = rng.standard_normal((10_000, 512)).astype(np.float32)
+    rows = rng.choice(10_000, len(faces), replace=False)
+    G[rows] = oemb / np.linalg.norm(oemb, axis=1, keepdims=True) + 0.02 * rng.standard_normal(oemb.shape).astype(np.float32)
+    G /= np.linalg.norm(G, axis=1, keepdims=True)
+    m = GalleryMatcher("cuda:0")
+    m.set_rows(list(range(10_000)), G, normalise=False)
+    ids, score, idx = m.match(np.stack([f.normed_embedding for f in faces]))
+    oi, _ = omatch.match_rows_fast(np.stack([omatch.renormalise(e / np.linalg.norm(e)) for e in oemb]), G)
+    assert np.array_equal(idx, oi) and np.array_equal(idx, rows)          # identical top-1 ids, the planted rows
+
+
+def test_eight_frame_batch_slot_path_vs_oracle(app):
+    """An 8-frame batch through the sync-free slot path (what bench.py times), every frame against the oracle."""
+    from make_golden import synth_frame
+    frs = np.ascontiguousarray(np.stack([synth_frame(360, 640, 40 + i) for i in range(8)]))
+    r = app.detect_embed_slots(torch.from_numpy(frs).cuda())
+    counts = r["counts"].cpu().numpy()
+    cap = r["bbox"].shape[1]
+    emb = r["embedding"].cpu().numpy().reshape(8, cap, 512)
+    total = 0
+    for i in range(8):
+        ob, os_, ok, oemb = oracle_pipeline(frs[i])
+        n = min(len(os_), cap)
+        assert counts[i] == n
+        total += n
+        if n:
+            np.testing.assert_allclose(r["bbox"][i, :n].cpu().numpy(), ob[:n], atol=5e-3)
+            np.testing.assert_allclose(r["det_score"][i, :n].cpu().numpy(), os_[:n], atol=5e-5)
+            e = emb[i, :n]
+            cos = (e * oemb[:n]).sum(1) / (np.linalg.norm(e, axis=1) * np.linalg.norm(oemb[:n], axis=1))
+            assert (1 - cos).max() < 1e-3, (i, cos)
+    assert total >= 4
