@@ -25,6 +25,7 @@ struct DcArgs {
     int regions_x, regions_y;
     const uint8_t* frames; int FH, FW;   // SRC == 1: u8 BGR frames [B,FH,FW,3], resized on the fly
     unsigned long long* stamps;          // diagnostic (FR_DBG_STAMPS): per-wave phase cycle sums, else NULL
+    const int32_t* counts; int cap;      // optional: image b is a real crop iff b % cap < counts[b / cap] (R-/O-Net slots)
 };
 
 #define DSTAMP(var)                                                                               \
@@ -102,6 +103,22 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
     const int per_img = a.regions_x * a.regions_y;
     const int nitems = per_img * ((a.B + G - 1) / G);
     const int item0 = blockIdx.x * RPB;
+    if (a.counts) {
+        // count-aware cascade: the R-Net / O-Net batch is nframes x cap crop SLOTS of which only counts[frame] hold a
+        // candidate (a prefix).  A block whose items cover empty slots only exits before any barrier: a 1-face frame
+        // no longer pays for 512 R-Net and 64 O-Net crops.  Outputs of empty slots stay unwritten (never read).
+        const int zlo = item0 / per_img;
+        int zhi = (item0 + RPB - 1) / per_img;
+        const int zmax = (a.B + G - 1) / G - 1;
+        if (zhi > zmax) zhi = zmax;
+        const int b_lo = zlo * G, b_hi = min((zhi + 1) * G, a.B);             // images [b_lo, b_hi)
+        bool any = false;
+        for (int f = b_lo / a.cap; f * a.cap < b_hi && !any; ++f) {
+            const int first = max(b_lo, f * a.cap);
+            any = first - f * a.cap < a.counts[f];
+        }
+        if (!any) return;
+    }
 
     auto stage_weights = [&](int st) {
         const float4v* src4 = reinterpret_cast<const float4v*>(wsrc + (int64_t)st * TG * C::CINP * C::CP);
@@ -546,11 +563,14 @@ static int launch_dc(const DcArgs& a0, hipStream_t s) {
 // Layer table (see mtcnn.py: layer ids).  Geometry is fixed by the MTCNN architecture.
 extern "C" int fr_dconv_mfma_f32(int layer, const float* x, const float* w, const float* bias, const float* slope,
                                  float* y, int B, int H, int W, const float* head_w, const float* head_b,
-                                 const uint8_t* frames, int FH, int FW, fr_stream_t stream) {
+                                 const uint8_t* frames, int FH, int FW, const int32_t* counts, int cap,
+                                 fr_stream_t stream) {
+    FR_REQUIRE(!counts || (cap > 0 && B % cap == 0 && layer >= 10), "fr_dconv_mfma_f32: counts need cap | B and an R-/O-Net layer");
     FR_REQUIRE(w && bias && y && B > 0 && H > 0 && W > 0, "fr_dconv_mfma_f32: bad argument");
     FR_REQUIRE((layer == 0) ? (frames && FH > 0 && FW > 0) : (x != nullptr), "fr_dconv_mfma_f32: no input");
     DcArgs a{x, w, bias, slope, y, head_w, head_b, B, H, W, 0, 0, 0, 0, frames, FH, FW,
-             (unsigned long long*)fr_dbg_ptr("FR_DBG_STAMPS")};          // NULL in the product build
+             (unsigned long long*)fr_dbg_ptr("FR_DBG_STAMPS"),           // NULL in the product build
+             counts, cap};
     hipStream_t s = fr_stream(stream);
     int rc = FR_OK;
     switch (layer) {

@@ -167,13 +167,14 @@ class MTCNNHIP:
     def _i32(self, *shape):
         return torch.empty(shape, dtype=torch.int32, device=self.device)
 
-    def _dconv(self, x, c, B, H, W, frames=None):
+    def _dconv(self, x, c, B, H, W, frames=None, counts=None, cap=0):
         ho, wo = c.out_hw(H, W)
         y = self._f32(B, ho, wo, c.nhead if c.nhead else c.cout)
         if isinstance(c, _MConv):
             fh, fw = (frames.shape[1], frames.shape[2]) if frames is not None else (0, 0)
             self.lib.fr_dconv_mfma_f32(c.layer, _lib.ptr(x), _lib.ptr(c.w), _lib.ptr(c.b), _lib.ptr(c.slope), _lib.ptr(y),
-                                       B, H, W, _lib.ptr(c.head_w), _lib.ptr(c.head_b), _lib.ptr(frames), fh, fw, self._s)
+                                       B, H, W, _lib.ptr(c.head_w), _lib.ptr(c.head_b), _lib.ptr(frames), fh, fw,
+                                       _lib.ptr(counts), cap, self._s)
         else:
             self.lib.fr_dconv_f32(_lib.ptr(x), _lib.ptr(c.w), _lib.ptr(c.b), _lib.ptr(c.slope), _lib.ptr(y), B, H, W,
                                   c.cin, c.cout, c.coutp, c.kh, c.kw, 1 if c.pool2 else 0, _lib.ptr(c.head_w),
@@ -205,21 +206,24 @@ class MTCNNHIP:
         head, h, w = self._dconv(x, self.p3, N, h, w)
         return head, h, w
 
-    def rnet(self, x, B):
-        x, h, w = self._dconv(x, self.r1, B, 24, 24)        # + fused 3x3/s2 pool -> 11x11
-        x, h, w = self._dconv(x, self.r2, B, h, w)          # + fused 3x3/s2 pool -> 4x4
-        x, h, w = self._dconv(x, self.r3, B, h, w)
-        x, h, w = self._dconv(x, self.r4, B, h, w)
-        x, h, w = self._dconv(x, self.r5, B, 1, 1)
+    def rnet(self, x, B, counts=None, cap=0):
+        """counts / cap: only the first counts[frame] of a frame's cap crop slots are computed (device-side)."""
+        k = dict(counts=counts, cap=cap)
+        x, h, w = self._dconv(x, self.r1, B, 24, 24, **k)   # + fused 3x3/s2 pool -> 11x11
+        x, h, w = self._dconv(x, self.r2, B, h, w, **k)     # + fused 3x3/s2 pool -> 4x4
+        x, h, w = self._dconv(x, self.r3, B, h, w, **k)
+        x, h, w = self._dconv(x, self.r4, B, h, w, **k)
+        x, h, w = self._dconv(x, self.r5, B, 1, 1, **k)
         return x.reshape(B, 6)
 
-    def onet(self, x, B):
-        x, h, w = self._dconv(x, self.o1, B, 48, 48)        # + fused 3x3/s2 pool -> 23x23
-        x, h, w = self._dconv(x, self.o2, B, h, w)          # + fused 3x3/s2 pool -> 10x10
-        x, h, w = self._dconv(x, self.o3, B, h, w)          # + fused 2x2/s2 pool -> 4x4
-        x, h, w = self._dconv(x, self.o4, B, h, w)
-        x, h, w = self._dconv(x, self.o5, B, h, w)
-        x, h, w = self._dconv(x, self.o6, B, 1, 1)
+    def onet(self, x, B, counts=None, cap=0):
+        k = dict(counts=counts, cap=cap)
+        x, h, w = self._dconv(x, self.o1, B, 48, 48, **k)   # + fused 3x3/s2 pool -> 23x23
+        x, h, w = self._dconv(x, self.o2, B, h, w, **k)     # + fused 3x3/s2 pool -> 10x10
+        x, h, w = self._dconv(x, self.o3, B, h, w, **k)     # + fused 2x2/s2 pool -> 4x4
+        x, h, w = self._dconv(x, self.o4, B, h, w, **k)
+        x, h, w = self._dconv(x, self.o5, B, h, w, **k)
+        x, h, w = self._dconv(x, self.o6, B, 1, 1, **k)
         return x.reshape(B, 16)
 
     # ---- cascade
@@ -274,7 +278,7 @@ class MTCNNHIP:
             crops = self._f32(B2, 24, 24, 4)
             lib.fr_crop_resize_norm(_lib.ptr(frames), N, H, W, _lib.ptr(b1), _lib.ptr(c1), self.cap_p, 24,
                                     _lib.ptr(crops), self._s)
-            head2 = self.rnet(crops, B2)
+            head2 = self.rnet(crops, B2, c1, self.cap_p)
             sb, ss, sa, sc = self._f32(N, self.cap_p, 4), self._f32(N, self.cap_p), self._f32(N, self.cap_p, 4), self._i32(N)
             prob2 = self._f32(N, self.cap_p) if trace is not None else None
             lib.fr_stage_select(_lib.ptr(b1), _lib.ptr(head2), 6, _lib.ptr(c1), N, self.cap_p, t1, _lib.ptr(sb),
@@ -289,7 +293,7 @@ class MTCNNHIP:
             crops3 = self._f32(B3, 48, 48, 4)
             lib.fr_crop_resize_norm(_lib.ptr(frames), N, H, W, _lib.ptr(b2), _lib.ptr(c2), self.cap_r, 48,
                                     _lib.ptr(crops3), self._s)
-            head3 = self.onet(crops3, B3)
+            head3 = self.onet(crops3, B3, c2, self.cap_r)
             tb, ts, ta, tc = self._f32(N, self.cap_r, 4), self._f32(N, self.cap_r), self._f32(N, self.cap_r, 14), self._i32(N)
             prob3 = self._f32(N, self.cap_r) if trace is not None else None
             lib.fr_stage_select(_lib.ptr(b2), _lib.ptr(head3), 16, _lib.ptr(c2), N, self.cap_r, t2, _lib.ptr(tb),

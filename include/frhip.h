@@ -210,10 +210,13 @@ int fr_dconv_f32(const float* x, const float* w, const float* bias, const float*
  * the group size; slope NULL = no PReLU.  Channel counts are padded to multiples of 4 (P-Net conv1 writes
  * 12 channels, R/O-Net conv1 read 4).  Layer 0 takes `frames` (u8 BGR [B,FH,FW,3]) instead of x: the
  * pyramid level (H x W) is resized on the fly inside the tile load, with the same arithmetic as
- * fr_pyramid_resize_norm.  Blocks walk several tiles, prefetching the next tile into registers. */
+ * fr_pyramid_resize_norm.  Blocks walk several tiles, prefetching the next tile into registers.
+ * counts / cap (R-/O-Net layers, optional): the batch is B / cap frames x cap crop slots and slot j of frame f
+ * holds a candidate iff j < counts[f] (device i32); blocks that cover empty slots only do no work and leave those
+ * outputs unwritten.  NULL: every image is computed. */
 int fr_dconv_mfma_f32(int layer, const float* x, const float* w, const float* bias, const float* slope,
                       float* y, int B, int H, int W, const float* head_w, const float* head_b,
-                      const uint8_t* frames, int FH, int FW, fr_stream_t stream);
+                      const uint8_t* frames, int FH, int FW, const int32_t* counts, int cap, fr_stream_t stream);
 /* max pool, ceil mode, f32 NHWC */
 int fr_maxpool_f32(const float* x, float* y, int B, int H, int W, int C, int k, int stride,
                    fr_stream_t stream);

@@ -164,3 +164,24 @@ def test_4k_frame_capacity_overflow_vs_oracle(det):
     np.testing.assert_allclose(scores[0, :n].cpu().numpy(), os_, atol=5e-5)
     np.testing.assert_allclose(boxes[0, :n].cpu().numpy(), ob, atol=2e-2)
     np.testing.assert_allclose(kps[0, :n].cpu().numpy(), ok, atol=2e-2)
+
+
+def test_count_aware_rnet_onet_equal_full_computation(det, monkeypatch):
+    """R-Net / O-Net compute only the crop slots that hold a candidate (device-side counts); the kept boxes must be
+    bit-identical to computing every slot, on frames whose stages are far from their capacities and on a batch in
+    which one frame has no candidate at all."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import synth_frame
+    frs = np.ascontiguousarray(np.stack([synth_frame(240, 320, s) for s in (4, 21, 5)]))
+    frs[1] = 0                                                        # a blank frame: zero candidates
+    x = torch.from_numpy(frs).cuda()
+    b1, s1, k1, c1 = det.detect_batch(x)
+    orig_r, orig_o = det.rnet, det.onet
+    monkeypatch.setattr(det, "rnet", lambda t, B, counts=None, cap=0: orig_r(t, B))
+    monkeypatch.setattr(det, "onet", lambda t, B, counts=None, cap=0: orig_o(t, B))
+    b0, s0, k0, c0 = det.detect_batch(x)
+    assert torch.equal(c0, c1) and int(c1[1]) == 0 and int(c1.sum()) >= 1
+    for f in range(3):
+        n = int(c1[f])
+        assert torch.equal(b0[f, :n], b1[f, :n]) and torch.equal(s0[f, :n], s1[f, :n]) and torch.equal(k0[f, :n], k1[f, :n])
