@@ -4,4 +4,5 @@ from facerecognition_infrenceengine_amd.face_analysis import Face, FaceAnalysis,
 from facerecognition_infrenceengine_amd.gallery import GalleryMatcher  # noqa: F401
 from facerecognition_infrenceengine_amd.processor import (CameraProcessor, EmbeddingManager,  # noqa: F401
                                                           FaceRecognitionProcessor, InMemoryStore)
+from facerecognition_infrenceengine_amd.camera import CameraManager  # noqa: F401
 from facerecognition_infrenceengine_amd.server import create_app  # noqa: F401

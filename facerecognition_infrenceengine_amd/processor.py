@@ -269,6 +269,70 @@ class FaceRecognitionProcessor:
                             "det_score": float(det[f]), "recognition_score": 0})
         return out
 
+    def recognize_batch(self, frames, company_id):
+        """Batch form for the camera batcher (``camera.CameraManager``): ``frames`` = list of same-sized BGR uint8
+        frames (one per camera).  ONE pass of the sync-free slot pipeline over the whole batch (pinned staging ->
+        copy stream -> detect -> align -> embed -> company view scan -> decision), one host synchronisation at the
+        end.  Returns a list (per frame) of lists of the dicts ``recognize`` returns, or None when the company has
+        no gallery (the reference returns the frame untouched then, infrenceServer.py:523-525)."""
+        import torch
+        from .ingest import FrameIngest
+        if self.face_detector is None:
+            self.initialize_detector()
+        det = self.face_detector
+        matcher, metadata = self.embedding_manager.get_matcher_for_company(company_id)
+        if len(matcher) == 0:
+            logger.warning("No embeddings found for company %s", company_id)
+            return None
+        arr = [np.ascontiguousarray(np.asarray(f)) for f in frames]
+        n, (h, w) = len(arr), arr[0].shape[:2]
+        if any(a.shape != (h, w, 3) or a.dtype != np.uint8 for a in arr):
+            raise ValueError("frames of a batch must be uint8 [H,W,3] of one size")
+        stages = self.__dict__.setdefault("_stages", {})
+        key = (n, h, w)
+        if key not in stages:
+            stages[key] = [FrameIngest(n, h, w, det.device, depth=2), 0]
+        ring, turn = stages[key]
+        stages[key][1] = turn + 1
+        with det._lock, torch.cuda.device(det.device):
+            host = ring.host_buffer(turn)
+            for i, a in enumerate(arr):
+                host[i] = a
+            dev, ready = ring.upload(turn)
+            r = det.detect_embed_slots(dev, ready_event=ready)
+            ring.release(turn)
+        matcher, metadata, idx, score = _match_fresh(self.embedding_manager, company_id, matcher, metadata,
+                                                     r["normed_embedding"])
+        dec = matcher.decide_device(idx, score, self.recognition_threshold)
+        cap = r["bbox"].shape[1]
+        counts = r["counts"].cpu().numpy()                                   # the one synchronisation
+        idx, score, dec = (t.cpu().numpy().reshape(n, cap) for t in (idx, score, dec))
+        bbox = r["bbox"].cpu().numpy().astype(int)                           # :531 truncation
+        dscore = r["det_score"].cpu().numpy()
+        out = []
+        for f in range(n):
+            faces = []
+            for j in range(int(counts[f])):
+                if dec[f, j] == 1:
+                    pid = matcher.ids[idx[f, j]]
+                    faces.append({"bbox": bbox[f, j], "person_id": pid, "person_info": metadata[pid],
+                                  "det_score": float(dscore[f, j]), "recognition_score": score[f, j]})
+                else:
+                    faces.append({"bbox": bbox[f, j], "person_id": None,
+                                  "person_info": {"name": "Unknown", "type": "unknown"},
+                                  "det_score": float(dscore[f, j]), "recognition_score": 0})
+            out.append(faces)
+        return out
+
+    def annotate(self, frame, results):
+        """Draw ``recognize`` / ``recognize_batch`` results onto a frame (colours of infrenceServer.py:546-553)."""
+        for r in results or ():
+            t = r["person_info"]["type"]
+            color = (0, 255, 0) if t == "employee" else (0, 255, 255) if t == "visitor" else (0, 0, 255)
+            frame = self.draw_enhanced_bounding_box(frame, r["bbox"], color, r["person_info"], r["det_score"],
+                                                    r["recognition_score"])
+        return frame
+
     def draw_enhanced_bounding_box(self, frame, bbox, color, person_info, detection_score, recognition_score):
         """The reference's HUD (infrenceServer.py:418-513) is presentation and out of scope; this
         draws a plain 2-px box so ``recognize_faces`` still returns a marked frame."""
@@ -285,11 +349,7 @@ class FaceRecognitionProcessor:
             results = self.recognize(frame, company_id)
             if results is None:
                 return frame
-            for r in results:
-                t = r["person_info"]["type"]
-                color = (0, 255, 0) if t == "employee" else (0, 255, 255) if t == "visitor" else (0, 0, 255)
-                frame = self.draw_enhanced_bounding_box(frame, r["bbox"], color, r["person_info"], r["det_score"],
-                                                        r["recognition_score"])
+            frame = self.annotate(frame, results)
         except Exception as e:                # errors are logged and swallowed (:560-563)
             logger.error("Error during face recognition: %s", e)
         return frame

@@ -363,3 +363,45 @@ def test_eight_frame_batch_slot_path_vs_oracle(app):
             cos = (e * oemb[:n]).sum(1) / (np.linalg.norm(e, axis=1) * np.linalg.norm(oemb[:n], axis=1))
             assert (1 - cos).max() < 1e-3, (i, cos)
     assert total >= 4
+
+
+def test_camera_batcher_equals_per_frame_recognition(app):
+    """N camera queues drained into ONE batch per turn must give, per source, exactly what the
+    reference's per-frame caller gets (recognize(frame) one frame at a time, infrenceServer.py:603-622): same faces,
+    same truncated boxes, same person ids, and per-company gallery views."""
+    import queue
+    from facerecognition_infrenceengine_amd.camera import CameraManager
+    from facerecognition_infrenceengine_amd.processor import EmbeddingManager, FaceRecognitionProcessor, InMemoryStore
+    from make_golden import synth_frame
+    frames = [synth_frame(240, 320, s) for s in (4, 5, 6, 21)]
+    # gallery: the faces of frames 0 and 2 are enrolled (company acme), plus noise rows and another company's rows
+    rng = np.random.default_rng(9)
+    store = InMemoryStore()
+    for i in range(30):
+        store.add_employee(f"n{i}", "acme" if i % 2 else "other", rng.standard_normal(512).astype(np.float32), name=f"N{i}")
+    for k in (0, 2):
+        for j, f in enumerate(app.get(frames[k])):
+            store.add_employee(f"face{k}_{j}", "acme", f.embedding, name=f"F{k}{j}")
+    mgr = EmbeddingManager(store=store, device="cuda:0")
+    proc = FaceRecognitionProcessor(mgr, face_detector=app)
+    want = [proc.recognize(f, "acme") for f in frames]
+    assert sum(r["person_id"] is not None for res in want for r in res) >= 1
+    cm = CameraManager(mgr, processor=proc)
+    cm.frame_queues = {s: queue.Queue(maxsize=2) for s in range(4)}
+    cm.result_queue = queue.Queue(maxsize=10)
+    cm.running = True
+    for s in range(4):
+        cm.frame_queues[s].put(frames[s].copy())
+    batch = cm.take_batch([0, 1, 2, 3])
+    assert len(batch) == 4
+    got = cm.process_batch(batch, "acme")
+    cm.running = False
+    assert cm.stats["largest_batch"] == 4
+    for a, b in zip(want, got):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert np.array_equal(x["bbox"], y["bbox"]) and x["person_id"] == y["person_id"]
+            assert x["det_score"] == y["det_score"] and float(x["recognition_score"]) == float(y["recognition_score"])
+    outs = [cm.result_queue.get_nowait() for _ in range(4)]
+    assert [s for s, _ in outs] == [0, 1, 2, 3] and all(o.shape == (240, 320, 3) for _, o in outs)
+    assert proc.recognize_batch(frames[:2], "nobody") is None          # unknown company: no gallery, frames untouched

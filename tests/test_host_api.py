@@ -134,3 +134,68 @@ def test_engine_fails_loudly_without_gpu():
         FaceAnalysis(name="x").prepare(ctx_id=0)
     with pytest.raises(FrError):
         GalleryMatcher("cuda:0")
+
+
+def test_camera_manager_batches_sources_and_keeps_reference_queue_semantics():
+    """CameraManager host logic with fake cameras and a fake processor (no GPU): one frame per source per turn, in
+    source order; frame queues of 2 drop when full; results are (source, frame) pairs; start/stop are idempotent."""
+    import queue
+    import time
+    from facerecognition_infrenceengine_amd.camera import CameraManager
+
+    class FakeCap:
+        def __init__(self, source, n):
+            self.source, self.n, self.i, self.exhausted = source, n, 0, False
+
+        def read(self):
+            if self.i >= self.n:
+                self.exhausted = True
+                time.sleep(0.001)
+                return False, None
+            self.i += 1
+            return True, np.full((4, 6, 3), self.source * 10 + self.i % 10, np.uint8)
+
+        def release(self):
+            self.released = True
+
+    class FakeProcessor:
+        def __init__(self):
+            self.batches = []
+
+        def recognize_batch(self, frames, company_id):
+            self.batches.append((len(frames), company_id))
+            time.sleep(0.002)
+            return [[{"tag": int(f[0, 0, 0])}] for f in frames]
+
+        def annotate(self, frame, res):
+            out = frame.copy(); out[0, 0, 0] = 255 - res[0]["tag"]
+            return out
+
+    proc = FakeProcessor()
+    caps = {}
+    cm = CameraManager(embedding_manager=None, processor=proc,
+                       capture_factory=lambda s: caps.setdefault(s, FakeCap(s, 40)))
+    # take_batch on hand-filled queues: order and "at most one per source"
+    cm.running = True
+    cm.frame_queues = {s: queue.Queue(maxsize=2) for s in (3, 1, 2)}
+    cm.result_queue = queue.Queue(maxsize=10)
+    cm.frame_queues[1].put(np.zeros((4, 6, 3), np.uint8)); cm.frame_queues[1].put(np.ones((4, 6, 3), np.uint8))
+    cm.frame_queues[3].put(np.full((4, 6, 3), 7, np.uint8))
+    b = cm.take_batch([3, 1, 2])
+    assert [s for s, _ in b] == [3, 1] and int(b[1][1][0, 0, 0]) == 0 and cm.frame_queues[1].qsize() == 1
+    res = cm.process_batch(b, "acme")
+    assert proc.batches == [(2, "acme")] and [r[0]["tag"] for r in res] == [7, 0]
+    assert [cm.result_queue.get_nowait()[0] for _ in range(2)] == [3, 1]
+    cm.running = False
+    # full run with threads
+    seen = []
+    cm.start_cameras([0, 1, 2], "acme", display=lambda s, f: seen.append((s, int(f[0, 0, 0]))))
+    cm.start_cameras([0, 1, 2], "acme")                      # second start is a no-op
+    deadline = time.time() + 10
+    while time.time() < deadline and not all(getattr(c, "exhausted", False) for c in caps.values()):
+        time.sleep(0.01)
+    time.sleep(0.1)
+    cm.stop_cameras(); cm.stop_cameras()
+    assert cm.stats["frames"] >= 3 and cm.stats["largest_batch"] >= 2 and all(n <= 3 for n, _ in proc.batches)
+    assert len(seen) >= 3 and {s for s, _ in seen} <= {0, 1, 2}
+    assert all(getattr(c, "released", False) for c in caps.values())
