@@ -377,7 +377,7 @@ def main():
             traffic = max(hits, key=lambda v: v.get("dispatches", 0))["hbm_bytes_per_launch_corrected"]
     except (OSError, KeyError, ValueError):
         pass
-    peak = MFMA_PEAK_TFLOPS_F8 if dom.endswith(", true>") and "conv_halo" in dom and dom.count(",") == 8 else MFMA_PEAK_TFLOPS
+    peak = MFMA_PEAK_TFLOPS_F8 if dom.startswith("conv_halo") and dom.endswith(", true, 8, 0>") else MFMA_PEAK_TFLOPS
     roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_source": f"{PMC_FILE}: rocprofv3 --pmc passes of tools/pmc_traffic.py (separate run; counters "

@@ -26,6 +26,7 @@ struct HaloP {
     int TH, tiles_per_img;      // output rows per tile, H / TH
     unsigned xbytes, wbytes;
     unsigned long long* stamps; // diagnostic build only (FR_DBG_STAMPS=<device ptr>): per-wave segment cycle sums
+    int stagger;                // diagnostic build only (FR_HALO_STAGGER): start delay of every second block, in 512-cycle units
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -42,6 +43,7 @@ __device__ __forceinline__ int pack_fp8x4(float a, float b, float c, float d) {
 }
 
 #define HK 64          // channels per chunk
+#define HALO_NW4_DEFAULT 0
 
 
 // scheduling pattern for one half step: 4+PT ds_read_b128 (+ ~3 address VALU each) spread over 4*PT MFMAs
@@ -76,21 +78,29 @@ __device__ __forceinline__ int pack_fp8x4(float a, float b, float c, float d) {
 // pair, fed by the same two ds_read_b128 per operand as the f16 step's two K = 32 MFMAs (lane quarter fq holds bytes
 // [16 fq, +16) and [64 + 16 fq, +16) of the row: the k order inside an MFMA is free as long as A and B agree), so the
 // LDS image, swizzle, DMA pattern and barrier structure are the f16 kernel's; the K loop has half as many steps.
-template <int WN, int NPT, int XROWS, int NXBUF, int MINW, bool STAMPS, bool LEAN = false, int NA = 4, bool F8 = false>
-__global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
+// NW: waves per block.  8 (512 threads) everywhere except the "lean4" variant <2,13,*,1,2,true,4,false,4>: FOUR waves
+// per block, each owning 64 couts x 6 pixel tiles + two cout tiles of the shared 13th pixel tile (26 accumulator tiles,
+// <= 256 VGPRs), still two blocks per CU.  Same LDS image and barrier structure, but a wave's register tile is twice as
+// large, so a K step reads 26 KB of fragments for 52 MFMAs instead of 18 KB for 26 (0.50 vs 0.69 KB of LDS traffic per
+// MFMA) and a barrier joins 4 waves instead of 8.
+template <int WN, int NPT, int XROWS, int NXBUF, int MINW, bool STAMPS, bool LEAN = false, int NA = 4, bool F8 = false, int NW = 8, int ABL = 0>
+__global__ __launch_bounds__(NW * 64, MINW) void conv_halo_kernel(HaloP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(!F8 || LEAN, "the fp8 variant exists for the lean schedule only");
     constexpr int ES = F8 ? 1 : 2;                     // bytes per element
     constexpr int CH = 128 / ES;                       // channels per 128-B chunk
     constexpr int BN = 16 * NA * WN;
-    constexpr int WP = 8 / WN;
+    constexpr int WP = NW / WN;
+    constexpr int NT = NW * 64;                       // threads per block
     // SPLIT (lean 196-pixel tiles): 13 pixel tiles over 4 pixel groups used to be 4+4+4+(1 real + 3 padding) tiles,
     // i.e. 16 MFMA tiles per wave for 12.25 useful.  Now every wave owns 3 pixel tiles x 64 couts and the 13th pixel
     // tile is shared by cout: wave (wn, wp) computes its couts [wn*64 + wp*16, +16) -> 13 MFMA tiles per wave.
     constexpr bool SPLIT = LEAN && WN == 2 && NPT == 13 && NA == 4;
-    constexpr int PT = SPLIT ? 3 : (NPT + WP - 1) / WP;
-    constexpr int NWI = BN / 64;                      // weight LDS-DMA instructions per thread per step
-    constexpr int NXI = XROWS / 64;                   // halo LDS-DMA instructions per thread per chunk
+    constexpr int PT = SPLIT ? 12 / WP : (NPT + WP - 1) / WP;
+    constexpr int XT = SPLIT ? NA / WP : 1;           // cout tiles of the shared 13th pixel tile per wave (1 or 2)
+    constexpr int NWI = BN / (8 * NW);                // weight LDS-DMA instructions per thread per step
+    constexpr int NXI = XROWS / (8 * NW);             // halo LDS-DMA instructions per thread per chunk
+    static_assert(BN % (8 * NW) == 0 && XROWS % (8 * NW) == 0 && NW % WN == 0, "tile / wave split");
     unsigned long long tA = 0, tB = 0, tC = 0, tD = 0;
     STAMP(tA);
     extern __shared__ __attribute__((aligned(16))) half_t lds[];
@@ -183,7 +193,9 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
     }
 
     float4v acc[NA][PT];
-    float4v accx = {0.f, 0.f, 0.f, 0.f};
+    float4v accx[XT];
+#pragma unroll
+    for (int t = 0; t < XT; ++t) accx[t] = float4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NA; ++i)
 #pragma unroll
@@ -195,12 +207,17 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
     //   mid:  lgkmcnt(0), counted vmcnt, barrier: W(q+1) landed, W(q)'s buffer free
     //         issue W(q+2) [+ next halo] | read (a0,b0)(q+1)    | MFMA half 1 (q)
     int4v a0[NA], b0[PT], a1[NA], b1[PT];       // 8 halves each, kept as 4 dwords (no per-element repacking)
-    int4v ax0 = {0, 0, 0, 0}, bx0 = {0, 0, 0, 0}, ax1 = {0, 0, 0, 0}, bx1 = {0, 0, 0, 0};   // SPLIT: 13th tile operands
-    auto read_x = [&](int4v& ax, int4v& bx, int q, int c, int toff, int kh, int kk) {
-        // A: this wave's 16-cout group of the shared tile (re-read from LDS: a register select by wp would be dynamic)
+    int4v ax0[XT], ax1[XT], bx0 = {0, 0, 0, 0}, bx1 = {0, 0, 0, 0};   // SPLIT: 13th tile operands
+#pragma unroll
+    for (int t = 0; t < XT; ++t) ax0[t] = ax1[t] = int4v{0, 0, 0, 0};
+    auto read_x = [&](int4v (&ax)[XT], int4v& bx, int q, int c, int toff, int kh, int kk) {
+        // A: this wave's 16-cout group(s) of the shared tile (re-read from LDS: a register select by wp would be dynamic)
         const half_t* wl = ws + (q & 1) * BN * HK + (wn * NA * 16) * HK;
-        const int row = wp * 16 + fr;
-        ax = *reinterpret_cast<const int4v*>(wl + row * HK + (((kk * 4 + fq) ^ (row & 7)) << 3));
+#pragma unroll
+        for (int t = 0; t < XT; ++t) {
+            const int row = (wp * XT + t) * 16 + fr;
+            ax[t] = *reinterpret_cast<const int4v*>(wl + row * HK + (((kk * 4 + fq) ^ (row & 7)) << 3));
+        }
         const char* xl = reinterpret_cast<const char*>(xs + (c & (NXBUF - 1)) * XROWS * HK) + toff * (HK * 2);
         const int key = (kbx + toff - 2 * kh) & 7;
         bx = *reinterpret_cast<const int4v*>(xl + hoffx + (((kk * 4 + fq) ^ key) << 4));
@@ -284,13 +301,13 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
                     }
                     if constexpr (SPLIT) {
                         read_x(ax0, bx0, q, c, toff, kh, 0); read_x(ax1, bx1, q, c, toff, kh, 1);
-                        accx = mfma8(ax0, ax1, bx0, bx1, accx);
+                        accx[0] = mfma8(ax0[0], ax1[0], bx0, bx1, accx[0]);
                     }
                     // pin the order above (hipcc otherwise hoists all 18 fragment reads = 72 VGPRs to the top of the step
                     // and spills): B + first A fragment, then per cout tile 3 MFMAs with the next tile's 2 reads between them
 #define FR_SGB_READ() do { __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } while (0)
 #define FR_SGB_MFMA() __builtin_amdgcn_sched_group_barrier(0x008, 1, 0)
-                    static_assert(!F8 || (PT == 3 && NA == 4 && SPLIT), "the fp8 schedule is written for the 4 x 3 + 1 tile split");
+                    static_assert(!F8 || (PT == 3 && NA == 4 && SPLIT && NW == 8), "the fp8 schedule is written for the 4 x 3 + 1 tile split");
 #pragma unroll
                     for (int g_ = 0; g_ < 2 * PT + 2; ++g_) FR_SGB_READ();
 #pragma unroll
@@ -311,27 +328,59 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
     if constexpr (LEAN) {
         static_assert(!LEAN || NXBUF == 1, "lean variant keeps one halo buffer");
         STAMP(tB);
+        if (FR_DEBUG && (p.stagger & 0xffff)) {   // experiment: de-phase blocks that may share a CU
+            const int mode = (p.stagger >> 8) & 255, n = p.stagger & 255;
+            const bool late = mode == 0 ? (int)blockIdx.x >= (int)gridDim.x / 2 : mode == 1 ? (blockIdx.x & 1) : ((blockIdx.x >> 3) & 1);
+            if (late) for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
+        }
         issue_x(0);
         issue_w(0);
+        constexpr int abl = ABL;      // debug build only: compile-time ablation bits (1 no MFMA, 2 no reads, 4 no W DMA, 8 no barrier)
         int tap = 0, c = 0, toff = 0, kw = 0, kh = 0;
         for (int q = 0; q < nq; ++q) {
             STAMP(t0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // W(q) (and a halo issued at the last chunk end)
             STAMP(t1);
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!(abl & 8)) __builtin_amdgcn_s_barrier();
             STAMP(t2);
-            if (q + 1 < nq) issue_w(q + 1);
+            if (q + 1 < nq && !(abl & 4)) issue_w(q + 1);
             STAMP(t3);
-            read_frags(a0, b0, q, c, toff, kh, 0);
-            if constexpr (SPLIT) read_x(ax0, bx0, q, c, toff, kh, 0);
+            if constexpr (!(abl & 2)) {
+                read_frags(a0, b0, q, c, toff, kh, 0);
+                if constexpr (SPLIT) read_x(ax0, bx0, q, c, toff, kh, 0);
+            }
+            if constexpr ((abl & 1) != 0) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) asm volatile("" ::"v"(a0[i]));
+#pragma unroll
+                for (int j = 0; j < PT; ++j) asm volatile("" ::"v"(b0[j]));
+                asm volatile("" ::"v"(ax0[0]), "v"(bx0));
+            } else {
             mfma_all(a0, b0);
-            if constexpr (SPLIT)
-                accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ax0), __builtin_bit_cast(half8, bx0), accx, 0, 0, 0);
-            read_frags(a1, b1, q, c, toff, kh, 1);
-            if constexpr (SPLIT) read_x(ax1, bx1, q, c, toff, kh, 1);
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int t = 0; t < XT; ++t)
+                    accx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ax0[t]), __builtin_bit_cast(half8, bx0), accx[t], 0, 0, 0);
+            }
+            }
+            if constexpr (!(abl & 2)) {
+                read_frags(a1, b1, q, c, toff, kh, 1);
+                if constexpr (SPLIT) read_x(ax1, bx1, q, c, toff, kh, 1);
+            }
+            if constexpr ((abl & 1) != 0) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) asm volatile("" ::"v"(a1[i]));
+#pragma unroll
+                for (int j = 0; j < PT; ++j) asm volatile("" ::"v"(b1[j]));
+                asm volatile("" ::"v"(ax1[0]), "v"(bx1));
+            } else {
             mfma_all(a1, b1);
-            if constexpr (SPLIT)
-                accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ax1), __builtin_bit_cast(half8, bx1), accx, 0, 0, 0);
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int t = 0; t < XT; ++t)
+                    accx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ax1[t]), __builtin_bit_cast(half8, bx1), accx[t], 0, 0, 0);
+            }
+            }
             STAMP(t4);
             ++tap; ++kw; ++toff;
             if (kw == 3) { kw = 0; toff += HW - 3; ++kh; }
@@ -431,7 +480,7 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
     const int m_base = n * p.H * p.W + y0 * p.W;
     __syncthreads();                                   // every wave is done with the operand buffers
     if (p.res) {
-        for (int e = tid; e < npx * CPR; e += 512) {
+        for (int e = tid; e < npx * CPR; e += NT) {
             const int px = e / CPR, cc = e - px * CPR;
             const int4v v = *reinterpret_cast<const int4v*>(p.res + (size_t)(m_base + px) * p.Cout + cout0 + cc * 8);
             *reinterpret_cast<int4v*>(ot + px * OP + cc * 8) = v;
@@ -475,11 +524,15 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
     }
     if constexpr (SPLIT) {
         const int px = 12 * 16 + fr;
-        if (px < npx) finish(accx, px, wn * NA * 16 + wp * 16 + fq * 4, bias_sel(px));
+        if (px < npx) {
+            const int bsel = bias_sel(px);
+#pragma unroll
+            for (int t = 0; t < XT; ++t) finish(accx[t], px, wn * NA * 16 + (wp * XT + t) * 16 + fq * 4, bsel);
+        }
     }
     __syncthreads();
     if (!F8 || p.y) {
-        for (int e = tid; e < npx * CPR; e += 512) {
+        for (int e = tid; e < npx * CPR; e += NT) {
             const int px = e / CPR, cc = e - px * CPR;
             const int4v v = *reinterpret_cast<const int4v*>(ot + px * OP + cc * 8);
             *reinterpret_cast<int4v*>(p.y + (size_t)(m_base + px) * p.Cout + cout0 + cc * 8) = v;
@@ -487,7 +540,7 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
     }
     if constexpr (F8) {
         if (p.y8) {                                    // fp8 copy for the next conv: 8 channels = 8 bytes per thread
-            for (int e = tid; e < npx * CPR; e += 512) {
+            for (int e = tid; e < npx * CPR; e += NT) {
                 const int px = e / CPR, cc = e - px * CPR;
                 const half8 h = *reinterpret_cast<const half8*>(ot + px * OP + cc * 8);
                 int2 o;
@@ -507,7 +560,7 @@ __global__ __launch_bounds__(512, MINW) void conv_halo_kernel(HaloP p) {
 #endif
 }
 
-template <int WN, int NPT, int XROWS, int NXBUF, int MINW, bool LEAN = false, int NA = 4, bool F8 = false>
+template <int WN, int NPT, int XROWS, int NXBUF, int MINW, bool LEAN = false, int NA = 4, bool F8 = false, int NW = 8, int ABL = 0>
 static int launch_halo(const HaloP& p, hipStream_t s) {
     constexpr int BN = 16 * NA * WN;
     constexpr size_t opnd = (size_t)(NXBUF * XROWS * HK + 2 * BN * HK) * sizeof(half_t);
@@ -517,19 +570,19 @@ static int launch_halo(const HaloP& p, hipStream_t s) {
     if constexpr (FR_DEBUG) {                  // stamped twin: debug build only
         if (p.stamps) {
             static FrDevLatch dl;
-            auto dk = conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, true, LEAN, NA, F8>;
+            auto dk = conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, true, LEAN, NA, F8, NW, ABL>;
             if (!fr_raise_lds(reinterpret_cast<const void*>(dk), lds, dl)) { fr_set_error("conv_halo: cannot raise dynamic LDS"); return FR_E_LAUNCH; }
-            dk<<<blocks, 512, lds, s>>>(p);
+            dk<<<blocks, NW * 64, lds, s>>>(p);
             return FR_OK;
         }
     }
     static FrDevLatch latch;
-    auto kern = conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, false, LEAN, NA, F8>;
+    auto kern = conv_halo_kernel<WN, NPT, XROWS, NXBUF, MINW, false, LEAN, NA, F8, NW, ABL>;
     if (!fr_raise_lds(reinterpret_cast<const void*>(kern), lds, latch)) {
         fr_set_error("conv_halo: cannot raise dynamic LDS to %zu bytes", lds);
         return FR_E_LAUNCH;
     }
-    kern<<<blocks, 512, lds, s>>>(p);
+    kern<<<blocks, NW * 64, lds, s>>>(p);
     return FR_OK;
 }
 
@@ -554,6 +607,7 @@ int fr_conv_halo_try(const fr_conv_args* a, hipStream_t s) {
     p.xbytes = (unsigned)((int64_t)a->B * a->H * a->W * a->Cin * 2);
     p.wbytes = (unsigned)((int64_t)a->Cout * 9 * a->Cin * 2);
     p.stamps = (unsigned long long*)fr_dbg_ptr("FR_DBG_STAMPS");        // always NULL in the product build
+    p.stagger = fr_dbg_int("FR_HALO_STAGGER", 0);
     int rc;
     if (a->H == 56) rc = launch_halo<1, 14, 384, 1, 4>(p, s);
     else if (a->H == 112) rc = launch_halo<1, 14, 512, 1, 4>(p, s);
@@ -561,8 +615,23 @@ int fr_conv_halo_try(const fr_conv_args* a, hipStream_t s) {
         // 28x28 and 14x14 layers run as two lean blocks per CU.  Debug build: FR_HALO_LEAN bit 0 / bit 1 = 0 selects
         // the pipelined one-block-per-CU schedule for 28x28 / 14x14 instead (kept as a measured alternative).
         const int lean = fr_dbg_int("FR_HALO_LEAN", 3);
-        if ((lean & 1) && a->H == 28) rc = launch_halo<2, 13, 320, 1, 4, true>(p, s);
-        else if ((lean & 2) && a->H == 14) rc = launch_halo<2, 13, 256, 1, 4, true>(p, s);
+        const int nw4 = fr_dbg_int("FR_HALO_NW4", HALO_NW4_DEFAULT);      // bit 0: 28x28, bit 1: 14x14 on the 4-wave lean variant
+        if ((lean & 1) && a->H == 28) rc = (nw4 & 1) ? launch_halo<2, 13, 320, 1, 2, true, 4, false, 4>(p, s) : launch_halo<2, 13, 320, 1, 4, true>(p, s);
+        else if (FR_DEBUG && a->H == 14 && (p.stagger >> 16)) {
+            if constexpr (FR_DEBUG) {
+                switch (p.stagger >> 16) {
+                    case 1: rc = launch_halo<2, 13, 256, 1, 4, true, 4, false, 8, 1>(p, s); break;
+                    case 2: rc = launch_halo<2, 13, 256, 1, 4, true, 4, false, 8, 2>(p, s); break;
+                    case 3: rc = launch_halo<2, 13, 256, 1, 4, true, 4, false, 8, 3>(p, s); break;
+                    case 4: rc = launch_halo<2, 13, 256, 1, 4, true, 4, false, 8, 4>(p, s); break;
+                    case 6: rc = launch_halo<2, 13, 256, 1, 4, true, 4, false, 8, 6>(p, s); break;
+                    case 7: rc = launch_halo<2, 13, 256, 1, 4, true, 4, false, 8, 7>(p, s); break;
+                    case 8: rc = launch_halo<2, 13, 256, 1, 4, true, 4, false, 8, 8>(p, s); break;
+                    default: rc = launch_halo<2, 13, 256, 1, 4, true, 4, false, 8, 15>(p, s); break;
+                }
+            } else rc = FR_E_INVALID;
+        }
+        else if ((lean & 2) && a->H == 14) rc = (nw4 & 2) ? launch_halo<2, 13, 256, 1, 2, true, 4, false, 4>(p, s) : launch_halo<2, 13, 256, 1, 4, true>(p, s);
         else if constexpr (FR_DEBUG) rc = (a->Cout % 256 == 0) ? launch_halo<4, 13, 320, 2, 2>(p, s) : launch_halo<2, 13, 320, 2, 2>(p, s);
         else rc = FR_E_INVALID;
     }
@@ -586,6 +655,7 @@ extern "C" int fr_conv_nhwc_f8(const fr_conv_f8_args* a, fr_stream_t stream) {
     p.xbytes = (unsigned)((int64_t)a->B * a->H * a->W * a->Cin);
     p.wbytes = (unsigned)((int64_t)a->Cout * 9 * a->Cin);
     p.stamps = (unsigned long long*)fr_dbg_ptr("FR_DBG_STAMPS");
+    p.stagger = 0;
     hipStream_t s = fr_stream(stream);
     const int rc = a->H == 28 ? launch_halo<2, 13, 320, 1, 4, true, 4, true>(p, s) : launch_halo<2, 13, 256, 1, 4, true, 4, true>(p, s);
     if (rc != FR_OK) return rc;

@@ -169,7 +169,7 @@ class IResNetHIP:
             e0.record()
             self.lib.fr_conv_nhwc_f8(ctypes.byref(a), _lib.stream_ptr())
             e1.record()
-            self.profile.append(("conv_halo_kernel<2, 13, %d, 1, 4, false, true, 4, true>" % (256 if H == 14 else 320),
+            self.profile.append(("conv_halo_kernel<2, 13, %d, 1, 4, false, true, 4, true, 8, 0>" % (256 if H == 14 else 320),
                                  2.0 * B * H * W * c.cout * 9 * c.cin, e0, e1))
         else:
             self.lib.fr_conv_nhwc_f8(ctypes.byref(a), _lib.stream_ptr())
@@ -232,11 +232,11 @@ class IResNetHIP:
             halo = None
             if c.k == 3 and c.stride == 1 and H == W and partial is None and c.cin % 64 == 0:
                 if H in (14, 28) and c.cout % 128 == 0:          # lean variant: BN = 128, two blocks per CU
-                    halo = "conv_halo_kernel<2, 13, %d, 1, 4, false, true, 4>" % (256 if H == 14 else 320)
+                    halo = "conv_halo_kernel<2, 13, %d, 1, 4, false, true, 4, false, 8, 0>" % (256 if H == 14 else 320)
                 elif H == 56 and c.cin == 64:
-                    halo = "conv_halo_kernel<1, 14, 384, 1, 4, false, false, 4>"
+                    halo = "conv_halo_kernel<1, 14, 384, 1, 4, false, false, 4, false, 8, 0>"
                 elif H == 112 and c.cin == 64 and c.cout == 64:
-                    halo = "conv_halo_kernel<1, 14, 512, 1, 4, false, false, 4>"
+                    halo = "conv_halo_kernel<1, 14, 512, 1, 4, false, false, 4, false, 8, 0>"
             variant = halo or "conv_mfma_kernel<%d, %s, true>" % (2 if c.cout % 128 == 0 else 1,
                                                                   "true" if c.cin == 8 else "false")
             kreal = 27 if c.cin == 8 else c.k * c.k * c.cin       # algorithmic K (stem: 3 real channels)

@@ -36,7 +36,9 @@ def umeyama(src, dst):
 
 
 def warp_affine_u8(img_u8, M, size=112):
-    """dst(x,y) = bilinear(img, M^-1 (x,y)); border 0; returns uint8 [size,size,C]."""
+    """dst(x,y) = bilinear(img, M^-1 (x,y)); border 0; returns uint8 [size,size,C].
+    PRODUCT DECISION: ideal float bilinear sampling (cv2.warpAffine uses 5-bit fixed-point weights; not available
+    here to pin against)."""
     H, W = img_u8.shape[:2]
     A = np.vstack([M, [0, 0, 1]])
     Ai = np.linalg.inv(A)

@@ -40,6 +40,9 @@ def pyramid_scales(h, w, minsize=20, factor=0.709):
     return scales
 
 
+# PRODUCT DECISION: ideal float32 bilinear (half-pixel centres, edge clamp, no antialias) for the pyramid levels and
+# the R-/O-Net crops.  The third-party path behind the reference (insightface/OpenCV) interpolates with fixed-point
+# weights / area averaging; neither is available here to pin against, so this file is the definition.
 def resize_bilinear(img, oh, ow):
     """img float32 [H,W,C] -> [oh,ow,C]; half-pixel centres, edge clamp."""
     H, W = img.shape[:2]
@@ -150,6 +153,10 @@ def detect(frame_bgr, pstate, rstate, ostate, minsize=20, factor=0.709,
             trace.setdefault("pnet_prob", []).append(prob)
             trace.setdefault("pnet_reg", []).append(reg)
         ys, xs = np.nonzero(prob >= t0)            # raster order
+        # PRODUCT DECISION, not part of the published MTCNN algorithm: a pyramid level hands on at most cap_scale
+        # candidates, the FIRST cap_scale cells in raster order (the HIP path has fixed-capacity lists).  On overflow
+        # (synthetic weights on a 4K frame: tests/test_gpu_detect.py::test_4k_...) cells further down the level are
+        # never candidates.  Trained weights on real frames stay far below the cap; raise cap_scale otherwise.
         ys, xs = ys[:cap_scale], xs[:cap_scale]
         if ys.size == 0:
             continue
