@@ -114,6 +114,21 @@ def c1_latency(app, device, n=30):
     return out
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on file descriptor 1 when a communicator is created; the driver wants ONE JSON line
+    on stdout.  Route fd 1 to fd 2 around the process-group set-up (and its first collective)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) with torch.distributed.run as a
     CHILD process - this process has not touched the GPU (importing torch does not) - pass rank 0's JSON line
@@ -178,13 +193,17 @@ def main():
     device = torch.device(f"cuda:{local_rank}")
     if world == 1 and (args.force_exchange or os.environ.get("FR_INIT_PG") == "1"):           # rehearsal: the N > 1 code path (RCCL collectives) with one rank
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+            dist.barrier()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        with stdout_to_stderr():
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            else:
+                dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.barrier()
 
     import warnings
     from facerecognition_infrenceengine_amd import FaceAnalysis, GalleryMatcher, _lib

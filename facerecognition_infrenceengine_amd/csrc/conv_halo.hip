@@ -95,7 +95,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_halo_kernel(HaloP p) {
     // SPLIT (lean 196-pixel tiles): 13 pixel tiles over 4 pixel groups used to be 4+4+4+(1 real + 3 padding) tiles,
     // i.e. 16 MFMA tiles per wave for 12.25 useful.  Now every wave owns 3 pixel tiles x 64 couts and the 13th pixel
     // tile is shared by cout: wave (wn, wp) computes its couts [wn*64 + wp*16, +16) -> 13 MFMA tiles per wave.
-    constexpr bool SPLIT = LEAN && WN == 2 && NPT == 13 && NA == 4;
+    constexpr bool SPLIT = LEAN && (WN == 2 || WN == 4) && NPT == 13 && NA == 4;
     constexpr int PT = SPLIT ? 12 / WP : (NPT + WP - 1) / WP;
     constexpr int XT = SPLIT ? NA / WP : 1;           // cout tiles of the shared 13th pixel tile per wave (1 or 2)
     constexpr int NWI = BN / (8 * NW);                // weight LDS-DMA instructions per thread per step
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_halo_kernel(HaloP p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the surplus weight DMA must not land in the epilogue tile
     } else
     if constexpr (LEAN) {
-        static_assert(!LEAN || NXBUF == 1, "lean variant keeps one halo buffer");
+        static_assert(NXBUF == 1 || NXBUF == 2, "lean variant: one halo buffer, or two (the 16-wave variant) so that the next chunk's halo lands under this chunk's MFMAs");
         STAMP(tB);
         if (FR_DEBUG && (p.stagger & 0xffff)) {   // experiment: de-phase blocks that may share a CU
             const int mode = (p.stagger >> 8) & 255, n = p.stagger & 255;
@@ -344,6 +344,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_halo_kernel(HaloP p) {
             if constexpr (!(abl & 8)) __builtin_amdgcn_s_barrier();
             STAMP(t2);
             if (q + 1 < nq && !(abl & 4)) issue_w(q + 1);
+            if constexpr (NXBUF == 2) { if (tap == 0 && c + 1 < nchunk) issue_x(c + 1); }   // lands during this chunk's 9 steps
             STAMP(t3);
             if constexpr (!(abl & 2)) {
                 read_frags(a0, b0, q, c, toff, kh, 0);
@@ -386,10 +387,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_halo_kernel(HaloP p) {
             if (kw == 3) { kw = 0; toff += HW - 3; ++kh; }
             if (tap == 9) {
                 tap = 0; kw = 0; toff = 0; kh = 0; ++c;
+                if constexpr (NXBUF == 1) {
                 if (c < nchunk) {                                    // reload the single halo buffer
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();                    // every wave is done reading chunk c-1
                     issue_x(c);
+                }
                 }
             }
             STAMP(t5);
@@ -630,6 +633,10 @@ int fr_conv_halo_try(const fr_conv_args* a, hipStream_t s) {
                     default: rc = launch_halo<2, 13, 256, 1, 4, true, 4, false, 8, 15>(p, s); break;
                 }
             } else rc = FR_E_INVALID;
+        }
+        else if (FR_DEBUG && a->H == 14 && a->Cout % 256 == 0 && fr_dbg_int("FR_HALO_W16", 0)) {
+            if constexpr (FR_DEBUG) rc = launch_halo<4, 13, 256, 2, 4, true, 4, false, 16>(p, s);   // one 16-wave block per CU, two halo buffers
+            else rc = FR_E_INVALID;
         }
         else if ((lean & 2) && a->H == 14) rc = (nw4 & 2) ? launch_halo<2, 13, 256, 1, 2, true, 4, false, 4>(p, s) : launch_halo<2, 13, 256, 1, 4, true>(p, s);
         else if constexpr (FR_DEBUG) rc = (a->Cout % 256 == 0) ? launch_halo<4, 13, 320, 2, 2>(p, s) : launch_halo<2, 13, 320, 2, 2>(p, s);

@@ -401,7 +401,9 @@ def test_camera_batcher_equals_per_frame_recognition(app):
         assert len(a) == len(b)
         for x, y in zip(a, b):
             assert np.array_equal(x["bbox"], y["bbox"]) and x["person_id"] == y["person_id"]
-            assert x["det_score"] == y["det_score"] and float(x["recognition_score"]) == float(y["recognition_score"])
+            assert x["det_score"] == y["det_score"]
+            # the embed net picks its kernels by batch size (split-K below 48 faces): scores agree to f16-conv rounding
+            assert abs(float(x["recognition_score"]) - float(y["recognition_score"])) < 1e-4
     outs = [cm.result_queue.get_nowait() for _ in range(4)]
     assert [s for s, _ in outs] == [0, 1, 2, 3] and all(o.shape == (240, 320, 3) for _, o in outs)
     assert proc.recognize_batch(frames[:2], "nobody") is None          # unknown company: no gallery, frames untouched

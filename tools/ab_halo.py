@@ -14,18 +14,19 @@ for (H, Cin, Cout) in ((14, 256, 256),):
     res = torch.randn((B, H, H, Cout), device="cuda").half()
     ys = {}
     def run(nw4, y, n):
-        os.environ["FR_HALO_NW4"] = str(nw4)
+        os.environ["FR_HALO_NW4"] = str(nw4 if nw4 != 16 else 0)
+        os.environ["FR_HALO_W16"] = "1" if nw4 == 16 else "0"
         a = _lib.ConvArgs(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), _lib.ptr(bias), _lib.ptr(slope), _lib.ptr(res), None,
                           B, H, H, Cin, Cout, 3, 3, 1, 1, H, H, 1, 1)
         for _ in range(n):
             lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
-    for nw4 in (0, 3):
+    for nw4 in (0, 16):
         ys[nw4] = torch.empty((B, H, H, Cout), dtype=torch.float16, device="cuda")
         run(nw4, ys[nw4], 3)
     torch.cuda.synchronize()
-    print(f"{H}x{H} {Cin}->{Cout}: outputs identical: {bool(torch.equal(ys[0], ys[3]))}")
+    print(f"{H}x{H} {Cin}->{Cout}: outputs identical: {bool(torch.equal(ys[0], ys[16]))}")
     fl = 2.0 * B * H * H * Cout * 9 * Cin
-    variants = [(0, 0)] + [(0, a << 16) for a in (1, 2, 3, 4, 6, 7, 8, 15)]
+    variants = [(0, 0), (16, 0)]
     best = {}
     for rnd in range(3):
         for nw4, stg in variants:
