@@ -121,7 +121,8 @@ def _dense_as_conv(w, k, c):
 
 class MTCNNHIP:
     def __init__(self, pstate, rstate, ostate, device="cuda:0", minsize=20, factor=0.709,
-                 thresholds=(0.6, 0.7, 0.7), cap_scale=2048, keep_scale=256, cap_p=512, cap_r=64, cap_o=16):
+                 thresholds=(0.6, 0.7, 0.7), cap_scale=2048, keep_scale=256, cap_p=512, cap_r=64, cap_o=16,
+                 fused_pnet=True):
         _lib.require_gpu()
         self.lib = _lib.load()
         self.device = torch.device(device)
@@ -138,6 +139,15 @@ class MTCNNHIP:
         hw = torch.cat([p["conv4_1.weight"].reshape(2, 32), p["conv4_2.weight"].reshape(4, 32)])
         hb = torch.cat([p["conv4_1.bias"], p["conv4_2.bias"]])
         self.p3 = _MConv(2, p["conv3.weight"], p["conv3.bias"], p["prelu3.weight"], d, head=(hw, hb))
+        # fused conv2 -> conv3 -> heads on the f16 matrix cores (split precision) + exact f32 re-evaluation of every
+        # cell that can pass the threshold (csrc/pnet_fused.hip): weights as (cout, tap, channel), 10 taps x 16 channels
+        self.fused_pnet = bool(fused_pnet)
+        w2p = torch.zeros((16, 10, 16)); w2p[:, :9, :10] = p["conv2.weight"].permute(0, 2, 3, 1).reshape(16, 9, 10)
+        w3p = torch.zeros((32, 10, 16)); w3p[:, :9, :16] = p["conv3.weight"].permute(0, 2, 3, 1).reshape(32, 9, 16)
+        self._p23 = tuple(t.to(torch.float32).contiguous().to(d) for t in (
+            w2p, p["conv2.bias"], p["prelu2.weight"], w3p, p["conv3.bias"], p["prelu3.weight"], hw.t().contiguous(), hb))
+        self.refine_margin = 2e-3           # in logit units, ~200x the split-precision error
+        self.refined_cells = None           # optional device int32[1]: cells re-evaluated exactly (diagnostics)
         self.r1 = _MConv(10, r["conv1.weight"], r["conv1.bias"], r["prelu1.weight"], d)
         self.r2 = _MConv(11, r["conv2.weight"], r["conv2.bias"], r["prelu2.weight"], d)
         self.r3 = _MConv(12, r["conv3.weight"], r["conv3.bias"], r["prelu3.weight"], d)
@@ -202,6 +212,13 @@ class MTCNNHIP:
         hs, ws = int(math.ceil(H * scale)), int(math.ceil(W * scale))
         # the pyramid level is resized inside P-Net conv1's tile load (no f32 level image in HBM)
         x, h, w = self._dconv(None, self.p1, N, hs, ws, frames=frames)
+        if self.fused_pnet:
+            t0 = self.thresholds[0]
+            head = self._f32(N, h - 4, w - 4, 6)
+            self.lib.fr_pnet23_split_f16(_lib.ptr(x), N, h, w, *[_lib.ptr(t) for t in self._p23], _lib.ptr(head),
+                                         math.log(t0 / (1.0 - t0)) - self.refine_margin, _lib.ptr(self.refined_cells),
+                                         self._s)
+            return head, h - 4, w - 4
         x, h, w = self._dconv(x, self.p2, N, h, w)
         head, h, w = self._dconv(x, self.p3, N, h, w)
         return head, h, w

@@ -185,3 +185,49 @@ def test_count_aware_rnet_onet_equal_full_computation(det, monkeypatch):
     for f in range(3):
         n = int(c1[f])
         assert torch.equal(b0[f, :n], b1[f, :n]) and torch.equal(s0[f, :n], s1[f, :n]) and torch.equal(k0[f, :n], k1[f, :n])
+
+
+def test_fused_split_f16_pnet_equals_f32_pnet():
+    """P-Net conv2+conv3+heads on the f16 matrix cores with split-precision operands + exact f32 re-evaluation of every
+    cell that can pass the threshold (csrc/pnet_fused.hip) against the all-f32 MFMA path, level by level:
+    * every head value within 1e-4 (the split-precision error bound the refine margin relies on, measured here);
+    * every cell the f32 path keeps (prob >= 0.6) carries f32-accurate values (1e-6) and is kept by the fused path, and
+      no other cell is: identical candidate sets;
+    * the whole cascade returns bit-identical boxes / scores / landmarks on several frames, incl. a 1080p one."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import synth_frame
+    from facerecognition_infrenceengine_amd import weights
+    from facerecognition_infrenceengine_amd.mtcnn import MTCNNHIP, pyramid_scales
+    st = weights.synth_mtcnn_states(seed=4321)
+    fused = MTCNNHIP(*st, device="cuda:0", fused_pnet=True)
+    plain = MTCNNHIP(*st, device="cuda:0", fused_pnet=False)
+    fused.refined_cells = torch.zeros(1, dtype=torch.int32, device="cuda")
+    total = kept = 0
+    worst = 0.0
+    for hw, seed in (((240, 320), 21), ((480, 640), 0), ((1080, 1920), 31), ((96, 128), 3)):
+        fr = torch.from_numpy(np.ascontiguousarray(np.stack([synth_frame(hw[0], hw[1], seed + k) for k in range(2)]))).cuda()
+        for s in pyramid_scales(*hw):
+            with torch.cuda.device("cuda:0"):
+                fused._s = plain._s = torch.cuda.current_stream().cuda_stream
+                hf, h1, w1 = fused.pnet_level(fr, s)
+                hp, h2, w2 = plain.pnet_level(fr, s)
+            assert (h1, w1) == (h2, w2) and hf.shape == hp.shape
+            d = (hf - hp).abs()
+            worst = max(worst, float(d.max()))
+            keep_p = (hp[..., 1] - hp[..., 0]) >= np.log(1.5)
+            keep_f = (hf[..., 1] - hf[..., 0]) >= np.log(1.5)
+            assert torch.equal(keep_p, keep_f)
+            if keep_p.any():
+                assert float(d[keep_p].max()) < 2e-6, float(d[keep_p].max())
+            total += keep_p.numel(); kept += int(keep_p.sum())
+        a = fused.detect_batch(fr); b = plain.detect_batch(fr)
+        assert torch.equal(a[3], b[3])
+        for f in range(fr.shape[0]):
+            n = int(a[3][f])
+            for x, y in zip(a[:3], b[:3]):
+                assert torch.equal(x[f, :n], y[f, :n])
+    assert worst < 1e-4, worst
+    refined = int(fused.refined_cells[0])
+    print(f"\nfused P-Net: max |head - f32 head| = {worst:.2e}; kept {kept} of {total} cells; re-evaluated exactly: {refined // 2} per pass")
+    assert kept >= 100 and refined >= kept
