@@ -26,6 +26,8 @@ struct DcArgs {
     const uint8_t* frames; int FH, FW;   // SRC == 1: u8 BGR frames [B,FH,FW,3], resized on the fly
     unsigned long long* stamps;          // diagnostic (FR_DBG_STAMPS): per-wave phase cycle sums, else NULL
     const int32_t* counts; int cap;      // optional: image b is a real crop iff b % cap < counts[b / cap] (R-/O-Net slots)
+    unsigned char* y_split;              // optional (layer 0): second copy of the output as split f16, 64 B per pixel =
+                                         // [hi ch0-7 | hi ch8-15 | lo ch0-7 | lo ch8-15] (x = hi + lo; channels 12-15 zero): pnet_fused.hip
 };
 
 #define DSTAMP(var)                                                                               \
@@ -404,6 +406,21 @@ __global__ __launch_bounds__(NW * 64) void dconv_mfma(DcArgs a) {
                             float* o = a.y + (((int64_t)n * Hp + py) * Wp + px) * COUT;
                             if constexpr (COUT % 4 == 0) {       // the lane's 4 consecutive channels: one 16-byte store
                                 if (coW + i * 16 < COUT) *reinterpret_cast<float4v*>(o + coW + i * 16) = v;
+                                if constexpr (COUT <= 16 && C::NT == 1) {
+                                    if (a.y_split) {             // split-f16 copy for the fused P-Net kernel (8 B hi + 8 B lo per lane)
+                                        const int ch0 = coW + i * 16;                 // 0, 4, 8, 12
+                                        half4 hi, lo;
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) {
+                                            const float x = ch0 + e < COUT ? v[e] : 0.f;
+                                            const half_t h = (half_t)x;
+                                            hi[e] = h; lo[e] = (half_t)(x - (float)h);
+                                        }
+                                        unsigned char* o2 = a.y_split + (((int64_t)n * Hp + py) * Wp + px) * 64 + (ch0 >> 3) * 16 + ((ch0 >> 2) & 1) * 8;
+                                        *reinterpret_cast<half4*>(o2) = hi;
+                                        *reinterpret_cast<half4*>(o2 + 32) = lo;
+                                    }
+                                }
                             } else {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e)
@@ -564,13 +581,14 @@ static int launch_dc(const DcArgs& a0, hipStream_t s) {
 extern "C" int fr_dconv_mfma_f32(int layer, const float* x, const float* w, const float* bias, const float* slope,
                                  float* y, int B, int H, int W, const float* head_w, const float* head_b,
                                  const uint8_t* frames, int FH, int FW, const int32_t* counts, int cap,
-                                 fr_stream_t stream) {
+                                 void* y_split, fr_stream_t stream) {
+    FR_REQUIRE(!y_split || layer == 0, "fr_dconv_mfma_f32: y_split is an output of layer 0 only");
     FR_REQUIRE(!counts || (cap > 0 && B % cap == 0 && layer >= 10), "fr_dconv_mfma_f32: counts need cap | B and an R-/O-Net layer");
     FR_REQUIRE(w && bias && y && B > 0 && H > 0 && W > 0, "fr_dconv_mfma_f32: bad argument");
     FR_REQUIRE((layer == 0) ? (frames && FH > 0 && FW > 0) : (x != nullptr), "fr_dconv_mfma_f32: no input");
     DcArgs a{x, w, bias, slope, y, head_w, head_b, B, H, W, 0, 0, 0, 0, frames, FH, FW,
              (unsigned long long*)fr_dbg_ptr("FR_DBG_STAMPS"),           // NULL in the product build
-             counts, cap};
+             counts, cap, (unsigned char*)y_split};
     hipStream_t s = fr_stream(stream);
     int rc = FR_OK;
     switch (layer) {

@@ -22,6 +22,8 @@
 // where a 16-pixel tile wraps an image row).  Weights sit in LDS pre-split in fragment order (a lane's 16 B contiguous).
 #include "common.h"
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
 #define P23_RH 8
 #define P23_RW 32
 #define P23_X1W (P23_RW + 4)              // 36
@@ -32,11 +34,14 @@
 #define P23_NT 512
 
 struct P23Args {
-    const float* x1;                      // conv1 output (PReLU + pool done): f32 [B, H1, W1, 12]
+    const float* x1;                      // conv1 output (PReLU + pool done): f32 [B, H1, W1, 12] (read by the exact re-evaluation)
+    const unsigned char* x1s;             // the same map as split f16, 64 B per pixel (layer 0's y_split): what this kernel streams
+    unsigned x1s_bytes;
     const float* w2; const float* b2; const float* s2;     // conv2: w [16][10 taps][16 ch] (tap 9, ch 12..15 zero), bias / slope [16]
     const float* w3; const float* b3; const float* s3;     // conv3: w [32][10][16], bias / slope [32]
     const float* hw; const float* hb;     // heads: hw [32][6], hb [6]
     float* head;                          // f32 [B, H3, W3, 6] = (logit0, logit1, reg0..3)
+    float* dl;                            // f32 [B, H3, W3]: logit1 - logit0 (what the re-evaluation pass scans)
     int B, H1, W1, H3, W3, tiles_x, tiles_y, ntiles;
 };
 
@@ -94,26 +99,40 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
     }
     const int csel = fq & 1;                                // which 8-channel chunk of the tap this lane feeds
 
+    // conv1 map window (12 x 36 pixels x 64 B) -> LDS by LDS-DMA: 27 pieces of 16 pixels (1 KB per wave-instruction),
+    // piece j by wave j % 8; a lane moves chunk position (lane & 3) of pixel 16 j + (lane >> 2) and fetches the SOURCE
+    // chunk (lane & 3) ^ swizzle(pixel), so the linear DMA image is the swizzled one; pixels outside the map read zeros.
+    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x1s, 0, a.x1s_bytes, 0x00020000);
+    int wy[4], wx[4], wc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = (wave + 8 * i) * 16 + (lane >> 2);
+        wy[i] = p / P23_X1W; wx[i] = p - wy[i] * P23_X1W;
+        wc[i] = ((lane & 3) ^ ((p >> 1) & 3)) * 16;
+    }
+    auto issue_window = [&](int tile) {
+        const int per = a.tiles_x * a.tiles_y;
+        const int n = tile / per, rem = tile - n * per;
+        const int ty0 = (rem / a.tiles_x) * P23_RH, tx0 = (rem % a.tiles_x) * P23_RW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = wave + 8 * i;
+            if (j < P23_X1PX / 16) {
+                const int gy = ty0 + wy[i], gx = tx0 + wx[i];
+                const unsigned off = (gy < a.H1 && gx < a.W1) ? (unsigned)(((n * a.H1 + gy) * a.W1 + gx) * 64 + wc[i]) : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(x1t + j * 1024), 16, off, 0, 0, 0);
+            }
+        }
+    };
+
+    __syncthreads();                                        // the weight fragments are staged
+    issue_window(blockIdx.x);
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int per = a.tiles_x * a.tiles_y;
         const int n = tile / per, rem = tile - n * per;
         const int ty0 = (rem / a.tiles_x) * P23_RH, tx0 = (rem % a.tiles_x) * P23_RW;
-        __syncthreads();                                    // previous tile's readers are done (and the weights are staged)
-        // ---- conv1 map window -> split f16 in LDS (4 items per pixel: channels 0-3, 4-7, 8-11, zeros for 12-15)
-        for (int e = tid; e < P23_X1PX * 4; e += P23_NT) {
-            const int p = e >> 2, g = e & 3;
-            const int yy = p / P23_X1W, xx = p - yy * P23_X1W;
-            const int gy = ty0 + yy, gx = tx0 + xx;
-            float4v v = {0.f, 0.f, 0.f, 0.f};
-            if (g < 3 && gy < a.H1 && gx < a.W1)
-                v = *reinterpret_cast<const float4v*>(a.x1 + (((size_t)n * a.H1 + gy) * a.W1 + gx) * 12 + g * 4);
-            half4 hi, lo;
-            p23_split4(v, hi, lo);
-            const unsigned o = p23_off(p, g >> 1) + (g & 1) * 8;
-            *reinterpret_cast<half4*>(x1t + o) = hi;
-            *reinterpret_cast<half4*>(x1t + (o ^ 32)) = lo;
-        }
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of the window have landed
+        __syncthreads();                                    // everyone's have; the previous tile's conv3 readers are done
         // ---- conv2 on the 10 x 34 window: 22 pixel tiles over 8 waves (3,3,3,3,3,3,2,2)
         {
             const int t0 = wave < 6 ? wave * 3 : 18 + (wave - 6) * 2, nt = wave < 6 ? 3 : 2;
@@ -160,6 +179,7 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
             }
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < a.ntiles) issue_window(tile + gridDim.x);      // next window lands under conv3 + heads
         // ---- conv3 on the 8 x 32 cells: 16 pixel tiles, 2 per wave, 2 cout tiles; then the heads
         {
             int pb[2];
@@ -214,9 +234,11 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
                 const int q = (wave * 2 + t) * 16 + fr;
                 const int gy = ty0 + (q >> 5), gx = tx0 + (q & 31);
                 if (fq == 0 && gy < a.H3 && gx < a.W3) {
-                    float* o = a.head + (((size_t)n * a.H3 + gy) * a.W3 + gx) * 6;
+                    const size_t cell = ((size_t)n * a.H3 + gy) * a.W3 + gx;
+                    float* o = a.head + cell * 6;
 #pragma unroll
-                    for (int h = 0; h < 6; ++h) o[h] = hs[h] + cst[288 + h];
+                    for (int h = 0; h < 6; ++h) { hs[h] += cst[288 + h]; o[h] = hs[h]; }
+                    a.dl[cell] = hs[1] - hs[0];
                 }
             }
         }
@@ -225,111 +247,144 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
 }
 
 // ---------------------------------------------------------------- exact f32 re-evaluation of the cells that matter
+// One persistent launch: a block scans a span of 4096 cells' logit differences (written by pnet23), appends the cells
+// with logit1 - logit0 >= logit_thr to a list in LDS (LDS atomics only: a single global counter saturates at ~90
+// appends/us and cost 1.1 ms per batch), then re-evaluates them FOUR per wave (16 lanes per cell: at ~1 % flagged cells
+// a wave that walked its own 64-cell chunk ran mostly empty and serial, 0.98 ms per batch).
+#define PREF_SPAN 4096
 struct PRefArgs {
     const float* x1; const float* w2; const float* b2; const float* s2; const float* w3; const float* b3; const float* s3;
-    const float* hw; const float* hb; float* head;
+    const float* hw; const float* hb; float* head; const float* dl;
     int B, H1, W1, H3, W3; float logit_thr;               // a cell is re-evaluated iff logit1 - logit0 >= logit_thr
-    int* counter;                                          // optional: number of re-evaluated cells (diagnostics), or NULL
+    int* counter;                                          // optional: accumulated number of re-evaluated cells (diagnostics), or NULL
 };
 
-__global__ __launch_bounds__(256) void pnet_refine_exact(PRefArgs a) {
-    __shared__ __attribute__((aligned(16))) float w2s[16 * 9 * 12];                     // [cout][tap][ch]
-    __shared__ __attribute__((aligned(16))) float w3s[32 * 9 * 16];
+__global__ __launch_bounds__(256) void pnet_refine_list(PRefArgs a) {
+    __shared__ __attribute__((aligned(16))) float w2s[16 * 164];                        // [cout][10 taps][16 ch] + 4 floats of row padding:
+    __shared__ __attribute__((aligned(16))) float w3s[32 * 164];                        // lanes = couts read 16 B at a 656-B stride, conflict-free
     __shared__ float cs[16 + 16 + 32 + 32 + 192 + 8];
-    __shared__ __attribute__((aligned(16))) float scr[4][5 * 5 * 12 + 9 * 16 + 32];     // per wave: conv1 window, conv2 activations, conv3 activations (476 floats: 16-B multiple)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < 16 * 9 * 12; e += 256) { const int co = e / 108, r = e - co * 108, tap = r / 12, ch = r - tap * 12; w2s[e] = a.w2[(co * 10 + tap) * 16 + ch]; }
-    for (int e = tid; e < 32 * 9 * 16; e += 256) { const int co = e / 144, r = e - co * 144, tap = r / 16, ch = r - tap * 16; w3s[e] = a.w3[(co * 10 + tap) * 16 + ch]; }
+    __shared__ __attribute__((aligned(16))) float scr[16][5 * 5 * 12 + 9 * 16];        // per 16-lane group: conv1 window, conv2 activations
+    __shared__ int lst[PREF_SPAN];
+    __shared__ int lcount;
+    const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;
+    for (int e = tid; e < 16 * 40; e += 256) reinterpret_cast<float4v*>(w2s)[(e / 40) * 41 + e % 40] = reinterpret_cast<const float4v*>(a.w2)[e];
+    for (int e = tid; e < 32 * 40; e += 256) reinterpret_cast<float4v*>(w3s)[(e / 40) * 41 + e % 40] = reinterpret_cast<const float4v*>(a.w3)[e];
     for (int e = tid; e < 16; e += 256) { cs[e] = a.b2[e]; cs[16 + e] = a.s2[e]; }
     for (int e = tid; e < 32; e += 256) { cs[32 + e] = a.b3[e]; cs[64 + e] = a.s3[e]; }
     for (int e = tid; e < 192; e += 256) cs[96 + e] = a.hw[e];
     for (int e = tid; e < 8; e += 256) cs[288 + e] = e < 6 ? a.hb[e] : 0.f;
-    __syncthreads();
-    float* xw = scr[wave];
+    float* xw = scr[grp];
     float* a2 = xw + 300;
-    float* a3 = a2 + 144;
     const long long ncell = (long long)a.B * a.H3 * a.W3;
-    const long long nchunk = (ncell + 63) / 64;
-    for (long long chunk = (long long)blockIdx.x * 4 + wave; chunk < nchunk; chunk += (long long)gridDim.x * 4) {
-        const long long cell = chunk * 64 + lane;
-        bool flag = false;
-        if (cell < ncell) {
-            const float2 l = *reinterpret_cast<const float2*>(a.head + cell * 6);
-            flag = (l.y - l.x) >= a.logit_thr;
+    for (long long span = (long long)blockIdx.x * PREF_SPAN; span < ncell; span += (long long)gridDim.x * PREF_SPAN) {
+    __syncthreads();                                       // the previous span's list has been consumed
+    if (tid == 0) lcount = 0;
+    __syncthreads();
+    for (int k = tid; k < PREF_SPAN; k += 256) {
+        const long long cell = span + k;
+        if (cell < ncell && a.dl[cell] >= a.logit_thr) lst[atomicAdd(&lcount, 1)] = (int)cell;
+    }
+    __syncthreads();
+    const int n_list = lcount;
+    if (a.counter && tid == 0 && n_list) atomicAdd(a.counter, n_list);
+    // every group of the block makes the same number of trips; idle ones work on a clamped cell without storing
+    // conv1 window 5 x 5 x 12 of a cell (always inside the map for a valid conv3 cell): 5 rows of 60 contiguous floats,
+    // fetched into registers ONE TRIP AHEAD so that the global latency hides under the current trip's arithmetic
+    float4v win[5];
+    auto fetch = [&](int i0) {
+        const int i = i0 + grp;
+        const int c = lst[i < n_list ? i : n_list - 1];
+        const int hw3 = a.H3 * a.W3;
+        const int n = c / hw3, r = c - n * hw3, y = r / a.W3, x = r - y * a.W3;
+        const float* src = a.x1 + (((size_t)n * a.H1 + y) * a.W1 + x) * 12 + (l16 < 15 ? l16 : 0) * 4;
+#pragma unroll
+        for (int py = 0; py < 5; ++py) win[py] = *reinterpret_cast<const float4v*>(src + (size_t)py * a.W1 * 12);
+    };
+    if (n_list) fetch(0);
+    for (int i0 = 0; i0 < n_list; i0 += 16) {
+        const int i = i0 + grp;
+        const bool live = i < n_list;
+        const int c = lst[live ? i : n_list - 1];
+        if (l16 < 15) {
+#pragma unroll
+            for (int py = 0; py < 5; ++py) *reinterpret_cast<float4v*>(xw + py * 60 + l16 * 4) = win[py];
         }
-        unsigned long long m = __ballot(flag);
-        if (a.counter && lane == 0 && m) atomicAdd(a.counter, __popcll(m));
-        while (m) {
-            const int bpos = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const long long c = chunk * 64 + bpos;
-            const int n = (int)(c / ((long long)a.H3 * a.W3));
-            const int r = (int)(c - (long long)n * a.H3 * a.W3);
-            const int y = r / a.W3, x = r - y * a.W3;
-            // conv1 window 5 x 5 x 12 (always inside the map for a valid conv3 cell)
-            for (int e = lane; e < 300; e += 64) {
-                const int p = e / 12, ch = e - p * 12, py = p / 5, px = p - py * 5;
-                xw[e] = a.x1[(((size_t)n * a.H1 + y + py) * a.W1 + x + px) * 12 + ch];
-            }
-            __builtin_amdgcn_wave_barrier();
-            // conv2 at the 3 x 3 positions x 16 couts = 144 outputs, plain f32 fma chains over (tap, channel): lane =
-            // (cout, row of positions): 48 lanes x 3 outputs that share the weight row (LDS reads as float4)
-            if (lane < 48) {
-                const int co = lane & 15, py = lane >> 4;
-                float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-                for (int tap = 0; tap < 9; ++tap) {
-                    const float4v* wp = reinterpret_cast<const float4v*>(w2s + (co * 9 + tap) * 12);
-                    const float4v* xp = reinterpret_cast<const float4v*>(xw + ((py + tap / 3) * 5 + tap % 3) * 12);
+        __builtin_amdgcn_wave_barrier();
+        if (i0 + 16 < n_list) fetch(i0 + 16);
+        // conv2 at the 3 x 3 positions: lane = cout, 9 plain f32 fma chains over (tap, channel)
+        {
+            float s[9];
 #pragma unroll
-                    for (int c4 = 0; c4 < 3; ++c4) {
-                        const float4v w = wp[c4], x0 = xp[c4], x1 = xp[3 + c4], x2 = xp[6 + c4];
+            for (int k = 0; k < 9; ++k) s[k] = 0.f;
+            for (int tap = 0; tap < 9; ++tap) {
+                const float4v* wp = reinterpret_cast<const float4v*>(w2s + l16 * 164 + tap * 16);
+                const float* xb = xw + ((tap / 3) * 5 + tap % 3) * 12;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { s0 = fmaf(x0[e], w[e], s0); s1 = fmaf(x1[e], w[e], s1); s2 = fmaf(x2[e], w[e], s2); }
+                for (int c4 = 0; c4 < 3; ++c4) {
+                    const float4v w = wp[c4];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        const float4v xv = *reinterpret_cast<const float4v*>(xb + ((k / 3) * 5 + k % 3) * 12 + c4 * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s[k] = fmaf(xv[e], w[e], s[k]);
                     }
                 }
-                const float b = cs[co], sl = cs[16 + co];
-                s0 += b; s1 += b; s2 += b;
-                a2[(py * 3 + 0) * 16 + co] = s0 > 0.f ? s0 : s0 * sl;
-                a2[(py * 3 + 1) * 16 + co] = s1 > 0.f ? s1 : s1 * sl;
-                a2[(py * 3 + 2) * 16 + co] = s2 > 0.f ? s2 : s2 * sl;
             }
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 32) {
-                float s = 0.f;
-                for (int tap = 0; tap < 9; ++tap) {
-                    const float4v* ap = reinterpret_cast<const float4v*>(a2 + tap * 16);
-                    const float4v* wp = reinterpret_cast<const float4v*>(w3s + (lane * 9 + tap) * 16);
+            const float b = cs[l16], sl = cs[16 + l16];
 #pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) {
-                        const float4v av = ap[c4], w = wp[c4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) s = fmaf(av[e], w[e], s);
-                    }
-                }
-                s += cs[32 + lane];
-                a3[lane] = s > 0.f ? s : s * cs[64 + lane];
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 6) {
-                float s = 0.f;
-                for (int cch = 0; cch < 32; ++cch) s = fmaf(a3[cch], cs[96 + cch * 6 + lane], s);
-                a.head[c * 6 + lane] = s + cs[288 + lane];
-            }
-            __builtin_amdgcn_wave_barrier();
+            for (int k = 0; k < 9; ++k) { const float v = s[k] + b; a2[k * 16 + l16] = v > 0.f ? v : v * sl; }
         }
+        __builtin_amdgcn_wave_barrier();
+        // conv3: couts l16 and l16 + 16; heads: 6 sums over the 32 activations, reduced across the 16 lanes
+        float act[2];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int co = l16 + 16 * h2;
+            float sacc = 0.f;
+            for (int tap = 0; tap < 9; ++tap) {
+                const float4v* ap = reinterpret_cast<const float4v*>(a2 + tap * 16);
+                const float4v* wp = reinterpret_cast<const float4v*>(w3s + co * 164 + tap * 16);
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const float4v av = ap[c4], w = wp[c4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sacc = fmaf(av[e], w[e], sacc);
+                }
+            }
+            sacc += cs[32 + co];
+            act[h2] = sacc > 0.f ? sacc : sacc * cs[64 + co];
+        }
+        float hs[6];
+#pragma unroll
+        for (int h = 0; h < 6; ++h) {
+            float v = fmaf(act[0], cs[96 + l16 * 6 + h], act[1] * cs[96 + (l16 + 16) * 6 + h]);
+            v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+            hs[h] = v + cs[288 + h];
+        }
+        if (live && l16 == 0) {
+            float* o = a.head + (size_t)c * 6;
+#pragma unroll
+            for (int h = 0; h < 6; ++h) o[h] = hs[h];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     }
 }
 
-extern "C" int fr_pnet23_split_f16(const float* x1, int B, int H1, int W1, const float* w2, const float* b2,
+extern "C" int fr_pnet23_split_f16(const float* x1, const void* x1s, int B, int H1, int W1, const float* w2, const float* b2,
                                    const float* s2, const float* w3, const float* b3, const float* s3, const float* hw,
                                    const float* hb, float* head, float refine_logit_thr, int32_t* refined_count,
-                                   fr_stream_t stream) {
-    FR_REQUIRE(x1 && w2 && b2 && s2 && w3 && b3 && s3 && hw && hb && head, "fr_pnet23_split_f16: null pointer");
+                                   void* workspace, size_t workspace_bytes, fr_stream_t stream) {
+    FR_REQUIRE(x1 && x1s && w2 && b2 && s2 && w3 && b3 && s3 && hw && hb && head, "fr_pnet23_split_f16: null pointer");
+    FR_REQUIRE((int64_t)B * H1 * W1 * 64 < (1ll << 31), "fr_pnet23_split_f16: the split conv1 map must stay below 2 GiB (got %lld bytes)", (long long)B * H1 * W1 * 64);
     FR_REQUIRE(B > 0 && H1 >= 5 && W1 >= 5, "fr_pnet23_split_f16: the conv1 map must be at least 5x5 (got %dx%d)", H1, W1);
     P23Args a;
-    a.x1 = x1; a.w2 = w2; a.b2 = b2; a.s2 = s2; a.w3 = w3; a.b3 = b3; a.s3 = s3; a.hw = hw; a.hb = hb; a.head = head;
+    a.x1 = x1; a.x1s = (const unsigned char*)x1s; a.x1s_bytes = (unsigned)((int64_t)B * H1 * W1 * 64); a.w2 = w2; a.b2 = b2; a.s2 = s2; a.w3 = w3; a.b3 = b3; a.s3 = s3; a.hw = hw; a.hb = hb; a.head = head;
     a.B = B; a.H1 = H1; a.W1 = W1; a.H3 = H1 - 4; a.W3 = W1 - 4;
     a.tiles_x = (a.W3 + P23_RW - 1) / P23_RW; a.tiles_y = (a.H3 + P23_RH - 1) / P23_RH;
+    const long long ncell = (long long)B * a.H3 * a.W3;
+    FR_REQUIRE(workspace && workspace_bytes >= (size_t)ncell * 4, "fr_pnet23_split_f16: workspace needs %lld bytes", ncell * 4);
+    a.dl = reinterpret_cast<float*>(workspace);
     const long long nt = (long long)B * a.tiles_x * a.tiles_y;
     FR_REQUIRE(nt < (1ll << 31), "fr_pnet23_split_f16: too many tiles");
     a.ntiles = (int)nt;
@@ -341,13 +396,11 @@ extern "C" int fr_pnet23_split_f16(const float* x1, int B, int H1, int W1, const
     pnet23_split_f16<<<grid, P23_NT, lds, s>>>(a);
     FR_CHECK_LAUNCH("pnet23_split_f16");
     PRefArgs r;
-    r.x1 = x1; r.w2 = w2; r.b2 = b2; r.s2 = s2; r.w3 = w3; r.b3 = b3; r.s3 = s3; r.hw = hw; r.hb = hb; r.head = head;
+    r.x1 = x1; r.w2 = w2; r.b2 = b2; r.s2 = s2; r.w3 = w3; r.b3 = b3; r.s3 = s3; r.hw = hw; r.hb = hb; r.head = head; r.dl = a.dl;
     r.B = B; r.H1 = H1; r.W1 = W1; r.H3 = a.H3; r.W3 = a.W3; r.logit_thr = refine_logit_thr; r.counter = refined_count;
-    const long long nchunk = ((long long)B * a.H3 * a.W3 + 63) / 64;
-    int g2 = (int)((nchunk + 3) / 4);
-    if (g2 > 2048) g2 = 2048;
-    if (g2 < 1) g2 = 1;
-    pnet_refine_exact<<<g2, 256, 0, s>>>(r);
-    FR_CHECK_LAUNCH("pnet_refine_exact");
+    long long g2 = (ncell + PREF_SPAN - 1) / PREF_SPAN;
+    if (g2 > 512) g2 = 512;
+    pnet_refine_list<<<(int)g2, 256, 0, s>>>(r);
+    FR_CHECK_LAUNCH("pnet_refine_list");
     return FR_OK;
 }

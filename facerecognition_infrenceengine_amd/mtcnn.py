@@ -177,14 +177,14 @@ class MTCNNHIP:
     def _i32(self, *shape):
         return torch.empty(shape, dtype=torch.int32, device=self.device)
 
-    def _dconv(self, x, c, B, H, W, frames=None, counts=None, cap=0):
+    def _dconv(self, x, c, B, H, W, frames=None, counts=None, cap=0, y_split=None):
         ho, wo = c.out_hw(H, W)
         y = self._f32(B, ho, wo, c.nhead if c.nhead else c.cout)
         if isinstance(c, _MConv):
             fh, fw = (frames.shape[1], frames.shape[2]) if frames is not None else (0, 0)
             self.lib.fr_dconv_mfma_f32(c.layer, _lib.ptr(x), _lib.ptr(c.w), _lib.ptr(c.b), _lib.ptr(c.slope), _lib.ptr(y),
                                        B, H, W, _lib.ptr(c.head_w), _lib.ptr(c.head_b), _lib.ptr(frames), fh, fw,
-                                       _lib.ptr(counts), cap, self._s)
+                                       _lib.ptr(counts), cap, _lib.ptr(y_split), self._s)
         else:
             self.lib.fr_dconv_f32(_lib.ptr(x), _lib.ptr(c.w), _lib.ptr(c.b), _lib.ptr(c.slope), _lib.ptr(y), B, H, W,
                                   c.cin, c.cout, c.coutp, c.kh, c.kw, 1 if c.pool2 else 0, _lib.ptr(c.head_w),
@@ -211,14 +211,18 @@ class MTCNNHIP:
         N, H, W, _ = frames.shape
         hs, ws = int(math.ceil(H * scale)), int(math.ceil(W * scale))
         # the pyramid level is resized inside P-Net conv1's tile load (no f32 level image in HBM)
-        x, h, w = self._dconv(None, self.p1, N, hs, ws, frames=frames)
-        if self.fused_pnet:
+        h, w = self.p1.out_hw(hs, ws)
+        if self.fused_pnet and N * h * w * 64 < 2 ** 31:          # the split map is addressed with 32-bit buffer offsets
+            xs = torch.empty((N, h, w, 64), dtype=torch.uint8, device=self.device)     # split-f16 copy of conv1's map
+            x, h, w = self._dconv(None, self.p1, N, hs, ws, frames=frames, y_split=xs)
             t0 = self.thresholds[0]
             head = self._f32(N, h - 4, w - 4, 6)
-            self.lib.fr_pnet23_split_f16(_lib.ptr(x), N, h, w, *[_lib.ptr(t) for t in self._p23], _lib.ptr(head),
+            ws = torch.empty(N * (h - 4) * (w - 4), dtype=torch.float32, device=self.device)
+            self.lib.fr_pnet23_split_f16(_lib.ptr(x), _lib.ptr(xs), N, h, w, *[_lib.ptr(t) for t in self._p23], _lib.ptr(head),
                                          math.log(t0 / (1.0 - t0)) - self.refine_margin, _lib.ptr(self.refined_cells),
-                                         self._s)
+                                         _lib.ptr(ws), ws.numel() * 4, self._s)
             return head, h - 4, w - 4
+        x, h, w = self._dconv(None, self.p1, N, hs, ws, frames=frames)
         x, h, w = self._dconv(x, self.p2, N, h, w)
         head, h, w = self._dconv(x, self.p3, N, h, w)
         return head, h, w

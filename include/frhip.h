@@ -213,21 +213,27 @@ int fr_dconv_f32(const float* x, const float* w, const float* bias, const float*
  * fr_pyramid_resize_norm.  Blocks walk several tiles, prefetching the next tile into registers.
  * counts / cap (R-/O-Net layers, optional): the batch is B / cap frames x cap crop slots and slot j of frame f
  * holds a candidate iff j < counts[f] (device i32); blocks that cover empty slots only do no work and leave those
- * outputs unwritten.  NULL: every image is computed. */
+ * outputs unwritten.  NULL: every image is computed.
+ * y_split (layer 0 only, optional): a second copy of the output as split f16, 64 B per pixel = [hi ch0-7 | hi ch8-15 |
+ * lo ch0-7 | lo ch8-15] with x = hi + lo and channels 12-15 zero - the operand format of fr_pnet23_split_f16. */
 int fr_dconv_mfma_f32(int layer, const float* x, const float* w, const float* bias, const float* slope,
                       float* y, int B, int H, int W, const float* head_w, const float* head_b,
-                      const uint8_t* frames, int FH, int FW, const int32_t* counts, int cap, fr_stream_t stream);
+                      const uint8_t* frames, int FH, int FW, const int32_t* counts, int cap, void* y_split,
+                      fr_stream_t stream);
 /* P-Net conv2 -> PReLU -> conv3 -> PReLU -> heads fused, on the f16 matrix cores with split-precision operands
  * (x = hi + lo in f16, three MFMAs per product term, f32 accumulate; ~1e-5 logit error), followed by an EXACT f32
  * re-evaluation of every cell whose logit1 - logit0 >= refine_logit_thr (pass ln(t/(1-t)) - 2e-3 for threshold t):
  * every cell that can be kept by fr_pnet_candidates then carries exact f32 logits and regressions, every other cell is
  * below the threshold by more than the approximation error.  x1: P-Net conv1 output (layer 0 of fr_dconv_mfma_f32),
  * f32 [B,H1,W1,12]; w2 [16][10][16] / w3 [32][10][16]: (cout, tap, channel) with tap 9 and unused channels zero;
+ * x1s: the same map as split f16 (y_split of layer 0), streamed into LDS by LDS-DMA.
  * b/s: bias and PReLU slope; hw [32][6], hb [6]: conv4_1|conv4_2.  head: f32 [B,H1-4,W1-4,6].
- * refined_count (optional device i32, accumulated): number of re-evaluated cells. */
-int fr_pnet23_split_f16(const float* x1, int B, int H1, int W1, const float* w2, const float* b2, const float* s2,
+ * refined_count (optional device i32, accumulated): number of re-evaluated cells.
+ * workspace: B*(H1-4)*(W1-4) * 4 bytes (logit differences, the re-evaluation pass scans them). */
+int fr_pnet23_split_f16(const float* x1, const void* x1s, int B, int H1, int W1, const float* w2, const float* b2, const float* s2,
                         const float* w3, const float* b3, const float* s3, const float* hw, const float* hb,
-                        float* head, float refine_logit_thr, int32_t* refined_count, fr_stream_t stream);
+                        float* head, float refine_logit_thr, int32_t* refined_count, void* workspace,
+                        size_t workspace_bytes, fr_stream_t stream);
 /* max pool, ceil mode, f32 NHWC */
 int fr_maxpool_f32(const float* x, float* y, int B, int H, int W, int C, int k, int stride,
                    fr_stream_t stream);

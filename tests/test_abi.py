@@ -51,7 +51,7 @@ def test_invalid_arguments_return_error_not_crash():
     with pytest.raises(_lib.FrError, match="unknown layer"):
         import ctypes as C
         one = C.c_void_p(16)          # never dereferenced: the layer id is rejected first
-        lib.fr_dconv_mfma_f32(99, one, one, one, None, one, 1, 8, 8, None, None, None, 0, 0, None, 0, None)
+        lib.fr_dconv_mfma_f32(99, one, one, one, None, one, 1, 8, 8, None, None, None, 0, 0, None, 0, None, None)
     with pytest.raises(_lib.FrError, match="bad argument"):
         lib.fr_conv_splitk_epilogue(None, 2, 10, 64, 7, 7, None, 0, None, None, None, None)
 
