@@ -125,7 +125,15 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
         }
     };
 
-    __syncthreads();                                        // the weight fragments are staged
+    __syncthreads();                                        // the weight fragments and constants are staged
+    half8 hwh, hwl;                                         // head weights as A fragments: row = head fr, k slot (fq, j) = cout 4fq+j | 16+4fq+(j-4)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int co = j < 4 ? 4 * fq + j : 16 + 4 * fq + (j - 4);
+        const float w = fr < 6 ? cst[96 + co * 6 + fr] : 0.f;
+        const half_t h = (half_t)w;
+        hwh[j] = h; hwl[j] = (half_t)(w - (float)h);
+    }
     issue_window(blockIdx.x);
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int per = a.tiles_x * a.tiles_y;
@@ -211,34 +219,39 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
                     }
                 }
             }
+            // heads on the matrix pipe: a lane's 8 activations (couts 4fq..4fq+3 of both cout tiles) ARE a B fragment of a
+            // K = 32 MFMA whose k slots are ordered (fq, [tile 0 x 4, tile 1 x 4]); A = the head weights in that k order
+            // (rows 0..5 = logit0, logit1, reg0..3; prepared once per block), split like every other operand.
+            const float4v b30 = *reinterpret_cast<const float4v*>(cst + 32 + 4 * fq), s30 = *reinterpret_cast<const float4v*>(cst + 64 + 4 * fq);
+            const float4v b31 = *reinterpret_cast<const float4v*>(cst + 48 + 4 * fq), s31 = *reinterpret_cast<const float4v*>(cst + 80 + 4 * fq);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                float hs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                float4v v0 = acc[t][0] + b30, v1 = acc[t][1] + b31;
+                half8 bh, bl;
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    const int c0 = ct * 16 + 4 * fq;
-                    const float4v bb = *reinterpret_cast<const float4v*>(cst + 32 + c0), ss = *reinterpret_cast<const float4v*>(cst + 64 + c0);
-                    float4v v = acc[t][ct] + bb;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float act = v[e] > 0.f ? v[e] : v[e] * ss[e];
-#pragma unroll
-                        for (int h = 0; h < 6; ++h) hs[h] = fmaf(act, cst[96 + (c0 + e) * 6 + h], hs[h]);
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = v0[e] > 0.f ? v0[e] : v0[e] * s30[e], x1 = v1[e] > 0.f ? v1[e] : v1[e] * s31[e];
+                    const half_t h0 = (half_t)x0, h1 = (half_t)x1;
+                    bh[e] = h0; bl[e] = (half_t)(x0 - (float)h0);
+                    bh[4 + e] = h1; bl[4 + e] = (half_t)(x1 - (float)h1);
                 }
-#pragma unroll
-                for (int h = 0; h < 6; ++h) {                               // sum over the 4 lane quarters (the other couts)
-                    hs[h] += __shfl_xor(hs[h], 16, 64);
-                    hs[h] += __shfl_xor(hs[h], 32, 64);
-                }
+                float4v d = {0.f, 0.f, 0.f, 0.f};
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwl, bh, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwh, bl, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwh, bh, d, 0, 0, 0);
+                // d[r] = head 4*fq + r of pixel fr (heads 6..15 are zero rows)
                 const int q = (wave * 2 + t) * 16 + fr;
                 const int gy = ty0 + (q >> 5), gx = tx0 + (q & 31);
-                if (fq == 0 && gy < a.H3 && gx < a.W3) {
+                if (fq < 2 && gy < a.H3 && gx < a.W3) {
                     const size_t cell = ((size_t)n * a.H3 + gy) * a.W3 + gx;
-                    float* o = a.head + cell * 6;
-#pragma unroll
-                    for (int h = 0; h < 6; ++h) { hs[h] += cst[288 + h]; o[h] = hs[h]; }
-                    a.dl[cell] = hs[1] - hs[0];
+                    float* o = a.head + cell * 6 + 4 * fq;
+                    const float4v hb4 = *reinterpret_cast<const float4v*>(cst + 288 + 4 * fq);
+                    const float o0 = d[0] + hb4[0], o1 = d[1] + hb4[1];
+                    *reinterpret_cast<float2*>(o) = make_float2(o0, o1);
+                    if (fq == 0) {
+                        *reinterpret_cast<float2*>(o + 2) = make_float2(d[2] + hb4[2], d[3] + hb4[3]);
+                        a.dl[cell] = o1 - o0;
+                    }
                 }
             }
         }
