@@ -17,9 +17,9 @@
 // Tile: 8 x 32 conv3 cells per pass of a block (8 waves); needs conv2 on 10 x 34 and the conv1 map on 12 x 36.
 // GEMM view (both convs): D[cout][pixel] = sum_k W[cout][k] X[pixel][k], k = (tap, channel) with 16 channels per tap
 // (conv1's 12 are zero-padded), K step 32 = two taps, 9 taps padded to 10 (zero weights).  A = weights, B = pixels:
-// a lane owns one pixel and 4 consecutive couts.  LDS pixel rows are 64 B = [hi ch0-7 | hi ch8-15 | lo ch0-7 | lo ch8-15]
-// with the 16-B chunk index XOR ((pixel >> 1) & 3): conflict-free ds_read_b128 fragments (2-way on 38 % of conv2's reads,
-// where a 16-pixel tile wraps an image row).  Weights sit in LDS pre-split in fragment order (a lane's 16 B contiguous).
+// a lane owns one pixel and 4 consecutive couts.  In LDS a pixel is 32 B (16 channels f16) in a hi plane and 32 B in a
+// lo plane: conflict-free ds_read_b128 fragments (2-way on 38 % of conv2's reads, where a 16-pixel tile wraps an image
+// row) with LINEAR addresses.  Weights sit in LDS pre-split in fragment order (a lane's 16 B contiguous).
 #include "common.h"
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -32,6 +32,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define P23_X2PX ((P23_RH + 2) * P23_X2W) // 340
 #define P23_X2T ((P23_X2PX + 15) / 16)    // 22 pixel tiles
 #define P23_NT 512
+#define P23_X1PL (448 * 32)               // bytes of one plane of the conv1 window (14 DMA pieces of 32 pixels)
+#define P23_X2PL (P23_X2PX * 32)          // bytes of one plane of the conv2 tile
 
 struct P23Args {
     const float* x1;                      // conv1 output (PReLU + pool done): f32 [B, H1, W1, 12] (read by the exact re-evaluation)
@@ -45,8 +47,6 @@ struct P23Args {
     int B, H1, W1, H3, W3, tiles_x, tiles_y, ntiles;
 };
 
-__device__ __forceinline__ unsigned p23_off(int p, int c) { return (unsigned)(p * 64 + ((c ^ ((p >> 1) & 3)) << 4)); }
-
 __device__ __forceinline__ void p23_split4(const float4v v, half4& hi, half4& lo) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -59,10 +59,10 @@ __device__ __forceinline__ void p23_split4(const float4v v, half4& hi, half4& lo
 __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* x1t = lds;                                        // [432 px][64 B]
-    char* x2t = x1t + P23_X1PX * 64;                        // [340 px][64 B]
-    char* wf = x2t + P23_X2PX * 64;                         // fragments: conv2 [5 ks][2 planes][64 lanes][16 B], conv3 [2 ct][5][2][64][16]
-    float* cst = reinterpret_cast<float*>(wf + 30 * 1024);  // b2[16] s2[16] b3[32] s3[32] hw[192] hb[8]
+    char* x1t = lds;                                        // hi plane [448 px][32 B] | lo plane [448][32] (432 used; 448 = 14 DMA pieces)
+    char* x2t = x1t + 2 * P23_X1PL;                         // hi plane [340 px][32 B] | lo plane
+    char* wf = x2t + 2 * P23_X2PL;                          // fragments: conv2 [5 ks][2 planes][64 lanes][16 B], conv3 [2 ct][5][2][64][16]
+    float* cst = reinterpret_cast<float*>(wf + 30 * 1024);  // b2[16] s2[16] b3[32] s3[32] hb[8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
 
@@ -84,31 +84,34 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
     }
     for (int e = tid; e < 16; e += P23_NT) { cst[e] = a.b2[e]; cst[16 + e] = a.s2[e]; }
     for (int e = tid; e < 32; e += P23_NT) { cst[32 + e] = a.b3[e]; cst[64 + e] = a.s3[e]; }
-    for (int e = tid; e < 192; e += P23_NT) cst[96 + e] = a.hw[e];
-    for (int e = tid; e < 8; e += P23_NT) cst[288 + e] = e < 6 ? a.hb[e] : 0.f;
+    for (int e = tid; e < 8; e += P23_NT) cst[96 + e] = e < 6 ? a.hb[e] : 0.f;
 
     // per-lane tap offsets of the 5 K steps (lane quarter fq < 2: tap 2ks, else tap 2ks+1; tap 9 does not exist: its
     // weights are zero, it reads tap 8's pixels)
+    // LDS addresses are LINEAR: a pixel row is 32 B in the hi plane and 32 B in the lo plane (a fixed distance apart, an
+    // immediate offset of the second ds_read), so a fragment address is (per-tile pixel base) + (per-K-step tap offset):
+    // one VALU add per read pair.  (The first version XOR-swizzled 64-B rows: 5-6 address VALU per read pair, and the
+    // kernel is VALU / LDS-issue bound, not MFMA bound.)  Same conflict profile as the swizzle (brute-forced).
     int off2[5], off3[5];
 #pragma unroll
     for (int ks = 0; ks < 5; ++ks) {
         int t = 2 * ks + (fq >> 1);
         if (t > 8) t = 8;
-        off2[ks] = (t / 3) * P23_X1W + t % 3;
-        off3[ks] = (t / 3) * P23_X2W + t % 3;
+        off2[ks] = ((t / 3) * P23_X1W + t % 3) * 32 + (fq & 1) * 16;       // bytes; + which 8-channel chunk of the tap this lane feeds
+        off3[ks] = ((t / 3) * P23_X2W + t % 3) * 32 + (fq & 1) * 16;
     }
-    const int csel = fq & 1;                                // which 8-channel chunk of the tap this lane feeds
 
-    // conv1 map window (12 x 36 pixels x 64 B) -> LDS by LDS-DMA: 27 pieces of 16 pixels (1 KB per wave-instruction),
-    // piece j by wave j % 8; a lane moves chunk position (lane & 3) of pixel 16 j + (lane >> 2) and fetches the SOURCE
-    // chunk (lane & 3) ^ swizzle(pixel), so the linear DMA image is the swizzled one; pixels outside the map read zeros.
+    // conv1 map window (12 x 36 pixels) -> LDS by LDS-DMA: per plane 14 pieces of 32 pixels x 32 B (1 KB per wave-
+    // instruction), piece j by wave j % 8; a lane moves 16-B chunk (lane & 1) of pixel 32 (j % 14) + (lane >> 1) from
+    // the 64-B global row [hi 32 B | lo 32 B]; pixels outside the map (and the 16 padding pixels of piece 13) read zeros.
     __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x1s, 0, a.x1s_bytes, 0x00020000);
     int wy[4], wx[4], wc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int p = (wave + 8 * i) * 16 + (lane >> 2);
-        wy[i] = p / P23_X1W; wx[i] = p - wy[i] * P23_X1W;
-        wc[i] = ((lane & 3) ^ ((p >> 1) & 3)) * 16;
+        const int j = wave + 8 * i, pl = j >= 14 ? 1 : 0;
+        const int p = (j - 14 * pl) * 32 + (lane >> 1);
+        wy[i] = p < P23_X1PX ? p / P23_X1W : 1 << 20; wx[i] = p % P23_X1W;
+        wc[i] = pl * 32 + (lane & 1) * 16;
     }
     auto issue_window = [&](int tile) {
         const int per = a.tiles_x * a.tiles_y;
@@ -117,10 +120,10 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int j = wave + 8 * i;
-            if (j < P23_X1PX / 16) {
+            if (j < 28) {
                 const int gy = ty0 + wy[i], gx = tx0 + wx[i];
                 const unsigned off = (gy < a.H1 && gx < a.W1) ? (unsigned)(((n * a.H1 + gy) * a.W1 + gx) * 64 + wc[i]) : 0x80000000u;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(x1t + j * 1024), 16, off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(x1t + (j >= 14 ? P23_X1PL + (j - 14) * 1024 : j * 1024)), 16, off, 0, 0, 0);
             }
         }
     };
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int co = j < 4 ? 4 * fq + j : 16 + 4 * fq + (j - 4);
-        const float w = fr < 6 ? cst[96 + co * 6 + fr] : 0.f;
+        const float w = fr < 6 ? a.hw[co * 6 + fr] : 0.f;
         const half_t h = (half_t)w;
         hwh[j] = h; hwl[j] = (half_t)(w - (float)h);
     }
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
             for (int t = 0; t < 3; ++t) {
                 int q = (t0 + t) * 16 + fr;
                 if (q >= P23_X2PX) q = 0;
-                pb[t] = (q / P23_X2W) * P23_X1W + q % P23_X2W;
+                pb[t] = ((q / P23_X2W) * P23_X1W + q % P23_X2W) * 32;
                 acc[t] = float4v{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
@@ -160,9 +163,9 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     if (t < nt) {
-                        const unsigned o = p23_off(pb[t] + off2[ks], csel);
-                        const half8 bhi = *reinterpret_cast<const half8*>(x1t + o);
-                        const half8 blo = *reinterpret_cast<const half8*>(x1t + (o ^ 32));
+                        const char* bp = x1t + (pb[t] + off2[ks]);
+                        const half8 bhi = *reinterpret_cast<const half8*>(bp);
+                        const half8 blo = *reinterpret_cast<const half8*>(bp + P23_X1PL);
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, acc[t], 0, 0, 0);
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, acc[t], 0, 0, 0);
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, acc[t], 0, 0, 0);
@@ -180,9 +183,9 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
                     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * ss[e];
                     half4 hi, lo;
                     p23_split4(v, hi, lo);
-                    const unsigned o = p23_off(q, fq >> 1) + (fq & 1) * 8;
-                    *reinterpret_cast<half4*>(x2t + o) = hi;
-                    *reinterpret_cast<half4*>(x2t + (o ^ 32)) = lo;
+                    char* o = x2t + q * 32 + fq * 8;
+                    *reinterpret_cast<half4*>(o) = hi;
+                    *reinterpret_cast<half4*>(o + P23_X2PL) = lo;
                 }
             }
         }
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int q = (wave * 2 + t) * 16 + fr;                     // y = q >> 5, x = q & 31
-                pb[t] = (q >> 5) * P23_X2W + (q & 31);
+                pb[t] = ((q >> 5) * P23_X2W + (q & 31)) * 32;
                 acc[t][0] = acc[t][1] = float4v{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
@@ -208,9 +211,9 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
                 }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const unsigned o = p23_off(pb[t] + off3[ks], csel);
-                    const half8 bhi = *reinterpret_cast<const half8*>(x2t + o);
-                    const half8 blo = *reinterpret_cast<const half8*>(x2t + (o ^ 32));
+                    const char* bp = x2t + (pb[t] + off3[ks]);
+                    const half8 bhi = *reinterpret_cast<const half8*>(bp);
+                    const half8 blo = *reinterpret_cast<const half8*>(bp + P23_X2PL);
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct) {
                         acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[ct], bhi, acc[t][ct], 0, 0, 0);
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
                 if (fq < 2 && gy < a.H3 && gx < a.W3) {
                     const size_t cell = ((size_t)n * a.H3 + gy) * a.W3 + gx;
                     float* o = a.head + cell * 6 + 4 * fq;
-                    const float4v hb4 = *reinterpret_cast<const float4v*>(cst + 288 + 4 * fq);
+                    const float4v hb4 = *reinterpret_cast<const float4v*>(cst + 96 + 4 * fq);
                     const float o0 = d[0] + hb4[0], o1 = d[1] + hb4[1];
                     *reinterpret_cast<float2*>(o) = make_float2(o0, o1);
                     if (fq == 0) {
@@ -401,7 +404,7 @@ extern "C" int fr_pnet23_split_f16(const float* x1, const void* x1s, int B, int 
     const long long nt = (long long)B * a.tiles_x * a.tiles_y;
     FR_REQUIRE(nt < (1ll << 31), "fr_pnet23_split_f16: too many tiles");
     a.ntiles = (int)nt;
-    constexpr size_t lds = (size_t)P23_X1PX * 64 + (size_t)P23_X2PX * 64 + 30 * 1024 + 296 * 4;
+    constexpr size_t lds = (size_t)2 * P23_X1PL + (size_t)2 * P23_X2PL + 30 * 1024 + 104 * 4;       // 81,568 B: two blocks per CU
     static FrDevLatch latch;
     if (!fr_raise_lds(reinterpret_cast<const void*>(pnet23_split_f16), lds, latch)) { fr_set_error("fr_pnet23_split_f16: cannot raise dynamic LDS"); return FR_E_LAUNCH; }
     hipStream_t s = fr_stream(stream);

@@ -197,9 +197,12 @@ class MTCNNHIP:
         self.lib.fr_maxpool_f32(_lib.ptr(x), _lib.ptr(y), B, H, W, C, k, s, self._s)
         return y, ho, wo
 
-    def _nms(self, boxes, scores, aux, naux, counts, L, nseg, seg_cap, seg_major, thr, mode, keep):
-        bo, so, co = self._f32(L, keep, 4), self._f32(L, keep), self._i32(L)
-        ao = self._f32(L, keep, max(naux, 1))
+    def _nms(self, boxes, scores, aux, naux, counts, L, nseg, seg_cap, seg_major, thr, mode, keep, out=None):
+        if out is None:
+            bo, so, co = self._f32(L, keep, 4), self._f32(L, keep), self._i32(L)
+            ao = self._f32(L, keep, max(naux, 1))
+        else:
+            bo, so, ao, co = out
         self.lib.fr_sort_nms(_lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(aux), naux, _lib.ptr(counts), L, nseg, seg_cap,
                              seg_major, thr, mode, keep, _lib.ptr(bo), _lib.ptr(so), _lib.ptr(ao), _lib.ptr(co), keep,
                              self._s)
@@ -267,6 +270,8 @@ class MTCNNHIP:
             assert nlev * self.keep_scale <= 4096, "too many pyramid levels for the merged NMS list"
             cs = self.cap_scale
             lb, ls, lr, lc = self._f32(nlev, N, cs, 4), self._f32(nlev, N, cs), self._f32(nlev, N, cs, 4), self._i32(nlev, N)
+            ksz = self.keep_scale
+            kb, ks, ka, kc = self._f32(nlev, N, ksz, 4), self._f32(nlev, N, ksz), self._f32(nlev, N, ksz, 4), self._i32(nlev, N)
             # Level 0 holds half of the pyramid's pixels; the remaining levels are small launches that cannot fill
             # 256 CUs on their own, so they run on a second HIP stream beside level 0 (joined before the NMS).
             main = torch.cuda.current_stream()
@@ -283,13 +288,15 @@ class MTCNNHIP:
                     prob = self._f32(N, hc, wc) if trace is not None else None
                     lib.fr_pnet_candidates(_lib.ptr(head), N, hc, wc, float(s), t0, cs, _lib.ptr(lb[li]), _lib.ptr(ls[li]),
                                            _lib.ptr(lr[li]), _lib.ptr(lc[li]), _lib.ptr(bc), _lib.ptr(prob), self._s)
+                    # per-level NMS 0.5 -> keep_scale survivors, right behind the level's own kernels on the level's
+                    # stream: the one-workgroup-per-list sorts (latency-bound) run under the other levels' P-Net
+                    self._nms(lb[li], ls[li], lr[li], 4, lc[li], N, 1, cs, 0, 0.5, 0, ksz, out=(kb[li], ks[li], ka[li], kc[li]))
                     if trace is not None:
                         trace.setdefault("pnet_head", []).append(head)
                         trace.setdefault("pnet_prob", []).append(prob)
             main.wait_stream(side)
             self._s = _lib.stream_ptr()
-            # per-level NMS 0.5 -> keep_scale survivors; then cross-level NMS 0.7 -> cap_p
-            kb, ks, ka, kc = self._nms(lb, ls, lr, 4, lc, nlev * N, 1, cs, 0, 0.5, 0, self.keep_scale)
+            # cross-level NMS 0.7 -> cap_p
             b1, s1, a1, c1 = self._nms(kb, ks, ka, 4, kc, N, nlev, self.keep_scale, 1, 0.7, 0, self.cap_p)
             lib.fr_box_refine(_lib.ptr(b1), _lib.ptr(a1), 4, _lib.ptr(c1), N, self.cap_p, 0, self._s)
             if trace is not None:
