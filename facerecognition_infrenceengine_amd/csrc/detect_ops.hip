@@ -203,12 +203,15 @@ __device__ __forceinline__ float softmax2_face(float a0, float a1) {
 }
 
 // head: f32 [N, hc, wc, 6] = (logit0, logit1, reg0..3).  Pass 1: per-block pass counts.
+// dl (optional, fused P-Net): f32 [N, hc, wc] approximate logit1 - logit0; a cell with dl < dl_min is certainly below the
+// threshold (pnet_fused.hip re-evaluated every cell at or above dl_min exactly), so its 24-byte head row is not read.
 __global__ __launch_bounds__(256) void pnet_count(const float* __restrict__ head, int cells, float thr,
-                                                  int32_t* __restrict__ block_counts, float* __restrict__ prob_out) {
+                                                  int32_t* __restrict__ block_counts, float* __restrict__ prob_out,
+                                                  const float* __restrict__ dl, float dl_min) {
     const int f = blockIdx.y, b = blockIdx.x;
     const int cell = b * 256 + threadIdx.x;
     bool pass = false;
-    if (cell < cells) {
+    if (cell < cells && (!dl || prob_out || dl[(int64_t)f * cells + cell] >= dl_min)) {
         const float* h = head + ((int64_t)f * cells + cell) * 6;
         float p = softmax2_face(h[0], h[1]);
         if (prob_out) prob_out[(int64_t)f * cells + cell] = p;
@@ -225,7 +228,8 @@ __global__ __launch_bounds__(256) void pnet_count(const float* __restrict__ head
 __global__ __launch_bounds__(256) void pnet_emit(const float* __restrict__ head, int cells, int wc, float scale,
                                                  float thr, int cap, const int32_t* __restrict__ block_counts,
                                                  float* __restrict__ boxes, float* __restrict__ scores,
-                                                 float* __restrict__ regs, int32_t* __restrict__ counts) {
+                                                 float* __restrict__ regs, int32_t* __restrict__ counts,
+                                                 const float* __restrict__ dl, float dl_min) {
     const int f = blockIdx.y, b = blockIdx.x, nb = gridDim.x;
     __shared__ int red[256];
     __shared__ int wsum[4];
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256) void pnet_emit(const float* __restrict__ head,
     bool pass = false;
     float p = 0.f;
     const float* h = head + ((int64_t)f * cells + (cell < cells ? cell : 0)) * 6;
-    if (cell < cells) {
+    if (cell < cells && (!dl || dl[(int64_t)f * cells + cell] >= dl_min)) {
         p = softmax2_face(h[0], h[1]);
         pass = p >= thr;
     }
@@ -274,15 +278,15 @@ __global__ __launch_bounds__(256) void pnet_emit(const float* __restrict__ head,
 
 extern "C" int fr_pnet_candidates(const float* head, int nframes, int hc, int wc, float scale, float thr, int cap,
                                   float* boxes, float* scores, float* regs, int32_t* counts, int32_t* block_counts,
-                                  float* prob_out, fr_stream_t stream) {
+                                  float* prob_out, const float* dl, float dl_min, fr_stream_t stream) {
     FR_REQUIRE(head && boxes && scores && regs && counts && block_counts, "fr_pnet_candidates: null pointer");
     FR_REQUIRE(nframes > 0 && hc > 0 && wc > 0 && cap > 0 && scale > 0.f, "fr_pnet_candidates: bad argument");
     const int cells = hc * wc;
     dim3 grid(fr_cdiv(cells, 256), nframes);
     hipStream_t s = fr_stream(stream);
-    pnet_count<<<grid, 256, 0, s>>>(head, cells, thr, block_counts, prob_out);
+    pnet_count<<<grid, 256, 0, s>>>(head, cells, thr, block_counts, prob_out, dl, dl_min);
     FR_CHECK_LAUNCH("pnet_count");
-    pnet_emit<<<grid, 256, 0, s>>>(head, cells, wc, scale, thr, cap, block_counts, boxes, scores, regs, counts);
+    pnet_emit<<<grid, 256, 0, s>>>(head, cells, wc, scale, thr, cap, block_counts, boxes, scores, regs, counts, dl, dl_min);
     FR_CHECK_LAUNCH("pnet_emit");
     return FR_OK;
 }

@@ -163,6 +163,14 @@ class MTCNNHIP:
                          torch.cat([o["dense6_1.bias"], o["dense6_2.bias"], o["dense6_3.bias"]]), None, d)
 
     @property
+    def _dl(self):
+        return getattr(self._tls, "dl", (None, 0.0))
+
+    @_dl.setter
+    def _dl(self, v):
+        self._tls.dl = v
+
+    @property
     def _s(self):
         return self._tls.s
 
@@ -224,7 +232,9 @@ class MTCNNHIP:
             self.lib.fr_pnet23_split_f16(_lib.ptr(x), _lib.ptr(xs), N, h, w, *[_lib.ptr(t) for t in self._p23], _lib.ptr(head),
                                          math.log(t0 / (1.0 - t0)) - self.refine_margin, _lib.ptr(self.refined_cells),
                                          _lib.ptr(ws), ws.numel() * 4, self._s)
+            self._dl = (ws, math.log(t0 / (1.0 - t0)) - self.refine_margin)     # pre-filter for fr_pnet_candidates
             return head, h - 4, w - 4
+        self._dl = (None, 0.0)
         x, h, w = self._dconv(None, self.p1, N, hs, ws, frames=frames)
         x, h, w = self._dconv(x, self.p2, N, h, w)
         head, h, w = self._dconv(x, self.p3, N, h, w)
@@ -286,8 +296,10 @@ class MTCNNHIP:
                     nblk = -(-hc * wc // 256)
                     bc = self._i32(N * nblk)
                     prob = self._f32(N, hc, wc) if trace is not None else None
+                    dl, dl_min = self._dl
                     lib.fr_pnet_candidates(_lib.ptr(head), N, hc, wc, float(s), t0, cs, _lib.ptr(lb[li]), _lib.ptr(ls[li]),
-                                           _lib.ptr(lr[li]), _lib.ptr(lc[li]), _lib.ptr(bc), _lib.ptr(prob), self._s)
+                                           _lib.ptr(lr[li]), _lib.ptr(lc[li]), _lib.ptr(bc), _lib.ptr(prob), _lib.ptr(dl),
+                                           dl_min, self._s)
                     # per-level NMS 0.5 -> keep_scale survivors, right behind the level's own kernels on the level's
                     # stream: the one-workgroup-per-list sorts (latency-bound) run under the other levels' P-Net
                     self._nms(lb[li], ls[li], lr[li], 4, lc[li], N, 1, cs, 0, 0.5, 0, ksz, out=(kb[li], ks[li], ka[li], kc[li]))

@@ -241,10 +241,12 @@ int fr_maxpool_f32(const float* x, float* y, int B, int H, int W, int C, int k, 
  * keeps cells with softmax face prob >= thr in raster order (first `cap`), emitting
  * box = floor((2*cell + {1,12}) / scale), score, reg.  boxes [nframes,cap,4], scores [nframes,cap],
  * regs [nframes,cap,4], counts i32 [nframes]; block_counts: i32 scratch [nframes*ceil(hc*wc/256)];
- * prob_out (optional) f32 [nframes,hc,wc]. */
+ * prob_out (optional) f32 [nframes,hc,wc].  dl / dl_min (optional, with fr_pnet23_split_f16): f32 [nframes,hc,wc]
+ * approximate logit1 - logit0; cells with dl < dl_min are known to be below the threshold and their head rows are
+ * not read (pass the workspace of fr_pnet23_split_f16 and its refine_logit_thr). */
 int fr_pnet_candidates(const float* head, int nframes, int hc, int wc, float scale, float thr, int cap,
                        float* boxes, float* scores, float* regs, int32_t* counts,
-                       int32_t* block_counts, float* prob_out, fr_stream_t stream);
+                       int32_t* block_counts, float* prob_out, const float* dl, float dl_min, fr_stream_t stream);
 /* per-list sort (descending score, ties by slot) + greedy NMS (mode 0: IoU, 1: IoMin).
  * Input list l = nseg segments of seg_cap slots (segment s at list index l*nseg+s, or s*L+l when
  * seg_major), counts i32 [L*nseg] (nseg*seg_cap <= 4096);
