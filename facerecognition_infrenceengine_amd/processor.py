@@ -291,6 +291,8 @@ class FaceRecognitionProcessor:
         stages = self.__dict__.setdefault("_stages", {})
         key = (n, h, w)
         if key not in stages:
+            while len(stages) >= 8:                       # a few (cameras present, frame size) shapes at most: drop the oldest ring
+                stages.pop(next(iter(stages)))
             stages[key] = [FrameIngest(n, h, w, det.device, depth=2), 0]
         ring, turn = stages[key]
         stages[key][1] = turn + 1
