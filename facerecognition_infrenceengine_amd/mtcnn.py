@@ -300,14 +300,18 @@ class MTCNNHIP:
                     lib.fr_pnet_candidates(_lib.ptr(head), N, hc, wc, float(s), t0, cs, _lib.ptr(lb[li]), _lib.ptr(ls[li]),
                                            _lib.ptr(lr[li]), _lib.ptr(lc[li]), _lib.ptr(bc), _lib.ptr(prob), _lib.ptr(dl),
                                            dl_min, self._s)
-                    # per-level NMS 0.5 -> keep_scale survivors, right behind the level's own kernels on the level's
-                    # stream: the one-workgroup-per-list sorts (latency-bound) run under the other levels' P-Net
-                    self._nms(lb[li], ls[li], lr[li], 4, lc[li], N, 1, cs, 0, 0.5, 0, ksz, out=(kb[li], ks[li], ka[li], kc[li]))
+                    # per-level NMS 0.5 -> keep_scale survivors.  Batches: right behind the level's own kernels on the
+                    # level's stream, so the one-workgroup-per-list sorts (latency-bound) run under the other levels'
+                    # P-Net.  Single frames are launch-bound: one launch for all levels after the loop instead.
+                    if N >= 8:
+                        self._nms(lb[li], ls[li], lr[li], 4, lc[li], N, 1, cs, 0, 0.5, 0, ksz, out=(kb[li], ks[li], ka[li], kc[li]))
                     if trace is not None:
                         trace.setdefault("pnet_head", []).append(head)
                         trace.setdefault("pnet_prob", []).append(prob)
             main.wait_stream(side)
             self._s = _lib.stream_ptr()
+            if N < 8:
+                self._nms(lb, ls, lr, 4, lc, nlev * N, 1, cs, 0, 0.5, 0, ksz, out=(kb, ks, ka, kc))
             # cross-level NMS 0.7 -> cap_p
             b1, s1, a1, c1 = self._nms(kb, ks, ka, 4, kc, N, nlev, self.keep_scale, 1, 0.7, 0, self.cap_p)
             lib.fr_box_refine(_lib.ptr(b1), _lib.ptr(a1), 4, _lib.ptr(c1), N, self.cap_p, 0, self._s)
