@@ -389,8 +389,12 @@ def main():
     # HBM traffic per launch of that kernel: PMC counters from a separate rocprofv3 pass (profiles/, see the
     # note inside the file for the gfx950 FETCH_SIZE correction); None when no record matches the kernel
     traffic = None
+    busy = None             # matrix-pipe busy fraction of that kernel from the SQ counters (same file; a separate --pmc run)
     try:
-        rec = json.load(open(os.path.join(ROOT, PMC_FILE)))["kernels"]
+        pmc = json.load(open(os.path.join(ROOT, PMC_FILE)))
+        rec = pmc["kernels"]
+        if pmc.get("_mfma_busy", {}).get("kernel") == dom:
+            busy = {k: pmc["_mfma_busy"][k] for k in ("whole_kernel", "k_loop", "source")}
         hits = [v for k, v in rec.items() if k.startswith(dom + " ") and "hbm_bytes_per_launch_corrected" in v]
         if hits:            # the kernel serves several layer shapes: take the one with the most launches
             traffic = max(hits, key=lambda v: v.get("dispatches", 0))["hbm_bytes_per_launch_corrected"]
@@ -401,6 +405,7 @@ def main():
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_source": f"{PMC_FILE}: rocprofv3 --pmc passes of tools/pmc_traffic.py (separate run; counters "
                                   "cannot be read from inside this process)" if traffic is not None else None,
+                "mfma_pipe_busy_pmc": busy,
                 "launches_per_step": calls, "avg_launch_us": round(secs / calls * 1e6, 2),
                 "algorithmic_gflop_per_launch": round(flops / calls / 1e9, 3)}
 
