@@ -577,15 +577,18 @@ static int launch_dc(const DcArgs& a0, hipStream_t s) {
     return FR_OK;
 }
 
+int fr_pnet_conv1_launch(const uint8_t* frames, int B, int FH, int FW, int H, int W, const float* w, const float* bias,
+                         const float* slope, float* y, void* y_split, hipStream_t s);
+
 // Layer table (see mtcnn.py: layer ids).  Geometry is fixed by the MTCNN architecture.
 extern "C" int fr_dconv_mfma_f32(int layer, const float* x, const float* w, const float* bias, const float* slope,
                                  float* y, int B, int H, int W, const float* head_w, const float* head_b,
                                  const uint8_t* frames, int FH, int FW, const int32_t* counts, int cap,
                                  void* y_split, fr_stream_t stream) {
-    FR_REQUIRE(!y_split || layer == 0, "fr_dconv_mfma_f32: y_split is an output of layer 0 only");
+    FR_REQUIRE(!y_split || layer == 0 || layer == 3, "fr_dconv_mfma_f32: y_split is an output of layer 0 only");
     FR_REQUIRE(!counts || (cap > 0 && B % cap == 0 && layer >= 10), "fr_dconv_mfma_f32: counts need cap | B and an R-/O-Net layer");
     FR_REQUIRE(w && bias && y && B > 0 && H > 0 && W > 0, "fr_dconv_mfma_f32: bad argument");
-    FR_REQUIRE((layer == 0) ? (frames && FH > 0 && FW > 0) : (x != nullptr), "fr_dconv_mfma_f32: no input");
+    FR_REQUIRE((layer == 0 || layer == 3) ? (frames && FH > 0 && FW > 0) : (x != nullptr), "fr_dconv_mfma_f32: no input");
     DcArgs a{x, w, bias, slope, y, head_w, head_b, B, H, W, 0, 0, 0, 0, frames, FH, FW,
              (unsigned long long*)fr_dbg_ptr("FR_DBG_STAMPS"),           // NULL in the product build
              counts, cap, (unsigned char*)y_split};
@@ -593,7 +596,10 @@ extern "C" int fr_dconv_mfma_f32(int layer, const float* x, const float* w, cons
     int rc = FR_OK;
     switch (layer) {
         //                  CIN COUT KH KW RH  RW  G NTB WN TG POOL PK RSY RSX NHEAD RPB SRC
-        case 0:  FR_REQUIRE(H >= 3 && W >= 3 && frames, "P1 needs frames and a level of at least 3x3");
+        case 0:  FR_REQUIRE(H >= 3 && W >= 3 && frames && slope, "P1 needs frames, PReLU slopes and a level of at least 3x3");
+                 rc = fr_pnet_conv1_launch(frames, B, FH, FW, H, W, w, bias, slope, y, y_split, s);      // pnet_conv1.hip
+                 break;
+        case 3:  FR_REQUIRE(H >= 3 && W >= 3 && frames, "P1 needs frames and a level of at least 3x3");
                  { const int v = fr_dbg_int("FR_P1_RPB", 8);
                  const bool big = (int64_t)((H - 2 + 15) / 16) * ((W - 2 + 31) / 32) * B >= 8192;
                  if (big && v == 2) rc = launch_dc<3, 12, 3, 3, 16, 32, 1, 1, 1, 9, 1, 2, 16, 32, 0, 2, 1>(a, s);

@@ -1,0 +1,278 @@
+// MTCNN P-Net conv1 (3 -> 10 channels, 3x3) + PReLU + 2x2/s2 ceil max pool, fed by the pyramid's bilinear resize
+// of the u8 BGR frame inside the tile load (the detector half of FaceAnalysis.get, /root/reference/infrenceServer.py:528;
+// architecture: SURVEY.md appendix A).  f32 end to end (the detector thresholds and truncates).
+//
+// Why its own kernel: on the 16x16x4 f32 MFMA (dconv_mfma.hip) this layer used 10 of 16 output columns and 27 of 36
+// K rows (47 % of the matrix work useful), and the epilogue ran on 16 pixels x 4 cout groups per wave instruction
+// with 37 % of the lanes on padding channels.  Here the matrix op is v_mfma_f32_4x4x1_16B_f32 with the A operand
+// BROADCAST (cbsz = 4): one instruction is a 4 (couts) x 64 (pixels, one per lane) x 1 (k) outer product,
+//   acc[cout 4g..4g+3][pixel lane] += W[k][4g+r] * X[pixel lane][k],
+// so K = 27 exactly, couts 12 of 12 (10 real), every lane of every VALU instruction of the epilogue is a pixel, and a
+// pixel's 12 channels sit in one lane: the pooled map leaves as 48 contiguous bytes per pixel (and 64 for the
+// split-f16 copy).  All 81 (k, cout group) weight quads live in SIX VGPRs: slot c = 3k + g sits in lanes
+// 4 (c % 16) .. +3 of register c / 16 and is selected by the instruction's ABID field.
+// The sum runs over k = (kh, kw, channel) ascending, one fma per k: the same chain as the 16x16x4 form.
+//
+// Tile: (4 RPW) rows x 64 columns of conv pixels per 4-wave block; wave w owns rows 4w' = RPW w .. + RPW - 1, a lane
+// owns one column.  Input tile (rows + 2) x 66 level pixels x 3 floats in LDS (lane stride 3 words: conflict-free);
+// an input row's 9 values (kw, channel) are read once and feed the up to 3 output rows that use it.
+// Blocks are persistent over RPB tiles; the next tile's SOURCE BYTES are fetched under the current tile's MFMAs and
+// blended afterwards (same scheme and same arithmetic as the form this replaces).
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+struct P1Args {
+    const uint8_t* frames; int B, FH, FW;      // u8 BGR frames [B,FH,FW,3]
+    int H, W;                                  // pyramid level size (resized on the fly)
+    const float* w;                            // [9 taps][4][16] f32 (the layer-0 packing of mtcnn._MConv)
+    const float* bias; const float* slope;     // [16]
+    float* y;                                  // pooled map f32 [B,Hp,Wp,12]
+    unsigned char* y_split;                    // optional split-f16 copy, 64 B per pixel (pnet_fused.hip)
+    int Ho, Wo, Hp, Wp, regions_x, regions_y;
+};
+
+typedef unsigned long long u64_unaligned __attribute__((aligned(1)));
+struct Lerp { int i0, i1; float w; };
+__device__ __forceinline__ Lerp lerp_coord(int d, float ratio, int n) {        // == detect_ops.hip lerp_coord
+    float f = ((float)d + 0.5f) * ratio - 0.5f;
+    float fl = floorf(f);
+    Lerp r;
+    r.w = f - fl;
+    int i = (int)fl;
+    r.i0 = min(max(i, 0), n - 1);
+    r.i1 = min(max(i + 1, 0), n - 1);
+    return r;
+}
+__device__ __forceinline__ float bilerp(float p00, float p01, float p10, float p11, float wx, float wy) {
+    float top = (1.0f - wx) * p00 + wx * p01;
+    float bot = (1.0f - wx) * p10 + wx * p11;
+    return (1.0f - wy) * top + wy * bot;
+}
+
+constexpr int P1_TW = 64, P1_IW = P1_TW + 2;
+
+template <int RPW, int RPB>
+__global__ __launch_bounds__(256) void pnet_conv1_kernel(P1Args a) {
+    constexpr int TH = 4 * RPW, IH = TH + 2, NPX = IH * P1_IW;
+    constexpr int NPF = (NPX + 255) / 256;
+    __shared__ float xin[NPX * 3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- weights: slot c = 3k + g (k = tap * 3 + channel) -> lanes 4 (c % 16) + r of register c / 16 hold W[k][4g + r]
+    float wreg[6];
+#pragma unroll
+    for (int v = 0; v < 6; ++v) {
+        const int c = v * 16 + (lane >> 2), r = lane & 3;
+        float x = 0.f;
+        if (c < 81) {
+            const int k = c / 3, g = c - k * 3, tap = k / 3, ch = k - tap * 3;
+            x = a.w[(tap * 4 + ch) * 16 + g * 4 + r];
+        }
+        wreg[v] = x;
+    }
+
+    const int per_img = a.regions_x * a.regions_y;
+    const int nitems = per_img * a.B;
+    const int item0 = blockIdx.x * RPB;
+    const float ryr = (float)a.FH / (float)a.H, rxr = (float)a.FW / (float)a.W;
+    const int frame_bytes = a.FH * a.FW * 3;
+
+    // ---- input tile: the prefetch keeps the RAW source bytes (two 8-byte row pieces per level pixel) and the lerp
+    // weights; conversion + blend happen in store_tile, after the current tile's MFMAs
+    unsigned long long rq0[NPF], rq1[NPF];
+    float rwx[NPF], rwy[NPF];
+    int rsh[NPF];            // 24: x1 = x0 + 1; 0: clamped right border; -1: pixel outside the level
+    int rpb[NPF];            // pull-back of the two row loads in bits (last frame's last bytes)
+    auto load_tile = [&](int item) {
+        const int n = item / per_img, rem = item - n * per_img;
+        const int ry = rem / a.regions_x, rx = rem - ry * a.regions_x;
+        const int y0 = ry * TH, x0 = rx * P1_TW;
+        const uint8_t* fbase = a.frames + (int64_t)n * frame_bytes;
+        const int lim = n == a.B - 1 ? frame_bytes - 8 : 0x7fffffff;
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int e = tid + u * 256;
+            const int iy = e / P1_IW, ix = e - iy * P1_IW;
+            const int yy = y0 + iy, xx = x0 + ix;
+            rsh[u] = -1; rq0[u] = rq1[u] = 0; rwx[u] = rwy[u] = 0.f; rpb[u] = 0;
+            if (e < NPX && yy < a.H && xx < a.W) {
+                const Lerp ly = lerp_coord(yy, ryr, a.FH), lx = lerp_coord(xx, rxr, a.FW);
+                // both corners of a row are 6 adjacent bytes (BGR BGR): ONE unaligned 8-byte load per source row; in the
+                // LAST frame the load is pulled back so that it never runs past the end of the buffer
+                const int o0 = (ly.i0 * a.FW + lx.i0) * 3, o1 = (ly.i1 * a.FW + lx.i0) * 3;
+                const int c0 = min(o0, lim), c1 = min(o1, lim);
+                rq0[u] = *reinterpret_cast<const u64_unaligned*>(fbase + c0);
+                rq1[u] = *reinterpret_cast<const u64_unaligned*>(fbase + c1);
+                rpb[u] = ((o0 - c0) * 8) | (((o1 - c1) * 8) << 8);
+                rwx[u] = lx.w; rwy[u] = ly.w;
+                rsh[u] = lx.i1 == lx.i0 ? 0 : 24;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int e = tid + u * 256;
+            if (e >= NPX) continue;
+            float v[3] = {0.f, 0.f, 0.f};
+            if (rsh[u] >= 0) {
+                const unsigned long long q0 = rq0[u] >> (rpb[u] & 0xff), q1 = rq1[u] >> (rpb[u] >> 8);
+                const unsigned l0 = (unsigned)q0, h0 = (unsigned)(q0 >> 32), l1 = (unsigned)q1, h1 = (unsigned)(q1 >> 32);
+                const bool two = rsh[u] != 0;                 // x1 = x0 + 1 (else the clamped border: x1 = x0)
+                // bytes of a row piece: B0 G0 R0 B1 | G1 R1 . .  ; output order R, G, B
+                const float a00[3] = {(float)((l0 >> 16) & 0xff), (float)((l0 >> 8) & 0xff), (float)(l0 & 0xff)};
+                const float a01[3] = {(float)((h0 >> 8) & 0xff), (float)(h0 & 0xff), (float)(l0 >> 24)};
+                const float a10[3] = {(float)((l1 >> 16) & 0xff), (float)((l1 >> 8) & 0xff), (float)(l1 & 0xff)};
+                const float a11[3] = {(float)((h1 >> 8) & 0xff), (float)(h1 & 0xff), (float)(l1 >> 24)};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float sv = bilerp(a00[c], two ? a01[c] : a00[c], a10[c], two ? a11[c] : a10[c], rwx[u], rwy[u]);
+                    v[c] = (sv - 127.5f) * 0.0078125f;
+                }
+            }
+            xin[e * 3 + 0] = v[0]; xin[e * 3 + 1] = v[1]; xin[e * 3 + 2] = v[2];
+        }
+    };
+
+    if (item0 < nitems) {
+        load_tile(item0);
+        store_tile();
+    }
+    float4v bias_r[3], slope_r[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        bias_r[g] = *reinterpret_cast<const float4v*>(a.bias + g * 4);
+        slope_r[g] = *reinterpret_cast<const float4v*>(a.slope + g * 4);
+    }
+    __syncthreads();
+
+    for (int rr = 0; rr < RPB; ++rr) {
+        const int item = item0 + rr;
+        if (item >= nitems) break;
+        const int n = item / per_img, rem = item - n * per_img;
+        const int ry = rem / a.regions_x, rx = rem - ry * a.regions_x;
+        const int y0 = ry * TH, x0 = rx * P1_TW;
+        const bool more = rr + 1 < RPB && item + 1 < nitems;
+        if (more) load_tile(item + 1);                   // global loads fly under this tile's MFMAs
+
+        float4v acc[RPW][3];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[r][g] = float4v{0.f, 0.f, 0.f, 0.f};
+        const float* xb = xin + ((wave * RPW) * P1_IW + lane) * 3;
+        // input row ir of the wave's band feeds output rows ir - kh (kh = 0..2): for an output row the k order is
+        // kh, then kw, then channel - ascending k
+        static_for<RPW + 2>([&](auto IR) {
+            constexpr int ir = decltype(IR)::value;
+            float xv[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) xv[q] = xb[ir * P1_IW * 3 + q];          // q = kw * 3 + channel
+            static_for<9>([&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+                static_for<3>([&](auto KH) {
+                    constexpr int kh = decltype(KH)::value, r = ir - kh;
+                    if constexpr (r >= 0 && r < RPW) {
+                        static_for<3>([&](auto G) {
+                            constexpr int g = decltype(G)::value;
+                            constexpr int c = (kh * 9 + q) * 3 + g;          // 3k + g, k = (kh*3 + kw)*3 + channel = kh*9 + q
+                            acc[r][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[c / 16], xv[q], acc[r][g], 4, c % 16, 0);
+                        });
+                    }
+                });
+            });
+        });
+
+        // ---- epilogue: bias + PReLU, 2x2/s2 ceil-mode max pool (rows in registers, columns by one lane exchange)
+        const int xcol = x0 + lane;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int yrow = y0 + wave * RPW + r;
+            const bool inside = yrow < a.Ho && xcol < a.Wo;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                float4v v = acc[r][g] + bias_r[g];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope_r[g][e];
+                acc[r][g] = inside ? v : float4v{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            }
+        }
+#pragma unroll
+        for (int rp = 0; rp < RPW / 2; ++rp) {
+            float4v pv[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float m = fmaxf(acc[2 * rp][g][e], acc[2 * rp + 1][g][e]);
+                    pv[g][e] = fmaxf(m, __shfl_xor(m, 1, 64));
+                }
+            }
+            const int py = (y0 + wave * RPW + 2 * rp) >> 1, px = xcol >> 1;
+            if ((lane & 1) == 0 && py < a.Hp && px < a.Wp) {
+                const int64_t pix = ((int64_t)n * a.Hp + py) * a.Wp + px;
+                float* o = a.y + pix * 12;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) *reinterpret_cast<float4v*>(o + g * 4) = pv[g];
+                if (a.y_split) {
+                    // split-f16 copy for the fused conv2/conv3 kernel: [hi ch0-7 | hi ch8-15 | lo ch0-7 | lo ch8-15],
+                    // channels 10..15 zero
+                    half8 hi[2], lo[2];
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        const float x = c < 10 ? pv[c >> 2][c & 3] : 0.f;
+                        const half_t h = (half_t)x;
+                        hi[c >> 3][c & 7] = h;
+                        lo[c >> 3][c & 7] = (half_t)(x - (float)h);
+                    }
+                    unsigned char* o2 = a.y_split + pix * 64;
+                    *reinterpret_cast<half8*>(o2) = hi[0];
+                    *reinterpret_cast<half8*>(o2 + 16) = hi[1];
+                    *reinterpret_cast<half8*>(o2 + 32) = lo[0];
+                    *reinterpret_cast<half8*>(o2 + 48) = lo[1];
+                }
+            }
+        }
+        if (more) {
+            __syncthreads();                 // every wave is done reading this tile
+            store_tile();
+            __syncthreads();
+        }
+    }
+}
+
+template <int RPW, int RPB>
+int launch_p1(P1Args a, hipStream_t s) {
+    constexpr int TH = 4 * RPW;
+    a.regions_x = (a.Wo + P1_TW - 1) / P1_TW;
+    a.regions_y = (a.Ho + TH - 1) / TH;
+    const int64_t nitems = (int64_t)a.regions_x * a.regions_y * a.B;
+    if (nitems >= (1ll << 31)) return FR_E_INVALID;
+    pnet_conv1_kernel<RPW, RPB><<<(unsigned)((nitems + RPB - 1) / RPB), 256, 0, s>>>(a);
+    return FR_OK;
+}
+
+}  // namespace
+
+// called by fr_dconv_mfma_f32 (layer 0); arguments checked there
+int fr_pnet_conv1_launch(const uint8_t* frames, int B, int FH, int FW, int H, int W, const float* w, const float* bias,
+                         const float* slope, float* y, void* y_split, hipStream_t s) {
+    P1Args a{frames, B, FH, FW, H, W, w, bias, slope, y, (unsigned char*)y_split, H - 2, W - 2, 0, 0, 0, 0};
+    a.Hp = (a.Ho + 1) / 2; a.Wp = (a.Wo + 1) / 2;
+    // big launches: 16-row tiles, blocks persistent over 8 tiles; small pyramid levels / single frames: 8-row tiles, one
+    // tile per block (too few tiles to fill 256 CUs: more, shorter blocks)
+    const int64_t tiles16 = (int64_t)((a.Ho + 15) / 16) * ((a.Wo + P1_TW - 1) / P1_TW) * B;
+    if (tiles16 >= 4096) return launch_p1<4, 8>(a, s);
+    if (tiles16 >= 512) return launch_p1<4, 1>(a, s);
+    return launch_p1<2, 1>(a, s);
+}
