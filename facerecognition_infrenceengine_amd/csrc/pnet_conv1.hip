@@ -60,12 +60,35 @@ __device__ __forceinline__ float bilerp(float p00, float p01, float p10, float p
 }
 
 constexpr int P1_TW = 64, P1_IW = P1_TW + 2;
+#ifndef P1_ABL
+#define P1_ABL 0
+#endif
 
+__device__ __forceinline__ float dpp_xor1(float v) {        // value of lane ^ 1 (quad_perm [1,0,3,2])
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_shr1(float v) {        // value of lane - 1 inside a row of 16 lanes (row_shr:1)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+}
+
+// v_max_f32 without the canonicalising self-max the compiler puts in front of fmaxf for values of unknown origin (MFMA
+// results): the operands here are never signalling NaNs
+__device__ __forceinline__ float vmax(float x, float y) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+
+// Lerp tables of a tile: the source rows / columns and weights of its (rows + 2) level rows and 66 level columns are
+// computed ONCE per tile by 84 threads (not once per pixel by everybody) and read back from LDS.
+//   row entry {i0 * FW * 3, i1 * FW * 3, wy, valid}    column entry {x0 * 3, wx, x1 != x0, valid}
 template <int RPW, int RPB>
-__global__ __launch_bounds__(256) void pnet_conv1_kernel(P1Args a) {
+__global__ __launch_bounds__(256, RPW == 4 ? 3 : 6) void pnet_conv1_kernel(P1Args a) {
     constexpr int TH = 4 * RPW, IH = TH + 2, NPX = IH * P1_IW;
     constexpr int NPF = (NPX + 255) / 256;
-    __shared__ float xin[NPX * 3];
+    constexpr int NTAB = IH + P1_IW;
+    __shared__ float xin[NPF * 256 * 3];      // slots past NPX (the last slot of some threads) land in the padding
+    __shared__ __attribute__((aligned(16))) int4v tab[2][NTAB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // ---- weights: slot c = 3k + g (k = tap * 3 + channel) -> lanes 4 (c % 16) + r of register c / 16 hold W[k][4g + r]
@@ -87,72 +110,118 @@ __global__ __launch_bounds__(256) void pnet_conv1_kernel(P1Args a) {
     const float ryr = (float)a.FH / (float)a.H, rxr = (float)a.FW / (float)a.W;
     const int frame_bytes = a.FH * a.FW * 3;
 
-    // ---- input tile: the prefetch keeps the RAW source bytes (two 8-byte row pieces per level pixel) and the lerp
-    // weights; conversion + blend happen in store_tile, after the current tile's MFMAs
-    unsigned long long rq0[NPF], rq1[NPF];
-    float rwx[NPF], rwy[NPF];
-    int rsh[NPF];            // 24: x1 = x0 + 1; 0: clamped right border; -1: pixel outside the level
-    int rpb[NPF];            // pull-back of the two row loads in bits (last frame's last bytes)
-    auto load_tile = [&](int item) {
-        const int n = item / per_img, rem = item - n * per_img;
-        const int ry = rem / a.regions_x, rx = rem - ry * a.regions_x;
-        const int y0 = ry * TH, x0 = rx * P1_TW;
-        const uint8_t* fbase = a.frames + (int64_t)n * frame_bytes;
-        const int lim = n == a.B - 1 ? frame_bytes - 8 : 0x7fffffff;
-#pragma unroll
-        for (int u = 0; u < NPF; ++u) {
-            const int e = tid + u * 256;
-            const int iy = e / P1_IW, ix = e - iy * P1_IW;
-            const int yy = y0 + iy, xx = x0 + ix;
-            rsh[u] = -1; rq0[u] = rq1[u] = 0; rwx[u] = rwy[u] = 0.f; rpb[u] = 0;
-            if (e < NPX && yy < a.H && xx < a.W) {
-                const Lerp ly = lerp_coord(yy, ryr, a.FH), lx = lerp_coord(xx, rxr, a.FW);
-                // both corners of a row are 6 adjacent bytes (BGR BGR): ONE unaligned 8-byte load per source row; in the
-                // LAST frame the load is pulled back so that it never runs past the end of the buffer
-                const int o0 = (ly.i0 * a.FW + lx.i0) * 3, o1 = (ly.i1 * a.FW + lx.i0) * 3;
-                const int c0 = min(o0, lim), c1 = min(o1, lim);
-                rq0[u] = *reinterpret_cast<const u64_unaligned*>(fbase + c0);
-                rq1[u] = *reinterpret_cast<const u64_unaligned*>(fbase + c1);
-                rpb[u] = ((o0 - c0) * 8) | (((o1 - c1) * 8) << 8);
-                rwx[u] = lx.w; rwy[u] = ly.w;
-                rsh[u] = lx.i1 == lx.i0 ? 0 : 24;
+    auto make_tables = [&](int item, int buf) __attribute__((always_inline)) {
+        if (tid < NTAB) {
+            const int n = item / per_img, rem = item - n * per_img;
+            const int ry = rem / a.regions_x, rx = rem - ry * a.regions_x;
+            int4v e;
+            if (tid < IH) {
+                const int yy = ry * TH + tid;
+                const Lerp l = lerp_coord(yy, ryr, a.FH);
+                e = int4v{l.i0 * a.FW * 3, l.i1 * a.FW * 3, __float_as_int(l.w), yy < a.H ? 1 : 0};
+            } else {
+                const int xx = rx * P1_TW + (tid - IH);
+                const Lerp l = lerp_coord(xx, rxr, a.FW);
+                e = int4v{l.i0 * 3, __float_as_int(l.w), l.i1 != l.i0 ? 1 : 0, xx < a.W ? 1 : 0};
             }
+            tab[buf][tid] = e;
         }
     };
-    auto store_tile = [&]() {
+
+    // ---- input tile: the prefetch keeps the RAW source bytes (two 8-byte row pieces per level pixel); conversion +
+    // blend happen in store_tile, after the current tile's MFMAs.  Per slot: 4 data registers + 1 of flags.
+    unsigned long long rq0[NPF], rq1[NPF];
+    int rfl[NPF];            // -1: pixel outside the level; else bit 0: x1 = x0 + 1 (0: clamped right border),
+                             // bits 8..15 / 16..23: pull-back of the two row loads in bits (last frame's last bytes)
+    int pos[NPF];            // table slots of the pixel: row | column << 16   (the same for every tile)
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+        const int e = min(tid + u * 256, NPX - 1), iy = e / P1_IW;         // slots past NPX: any valid table entry
+        pos[u] = iy | ((IH + e - iy * P1_IW) << 16);
+    }
+    // Both phases are branch-free per slot (a pixel outside the level loads offset 0 and is zeroed at the end), so the
+    // slots' table reads, loads and blends interleave instead of running as five dependent chains
+    bool edge = true;        // wave-uniform: some staged pixel is outside the level, sits on the clamped right border or
+                             // was loaded with a pull-back (otherwise the blend needs no selects and no shifts)
+    auto load_tile = [&](int item, int buf) __attribute__((always_inline)) {
+        const int n = item / per_img;
+        const uint8_t* fbase = a.frames + (int64_t)n * frame_bytes;
+        const bool last = n == a.B - 1;
+        const int lim = frame_bytes - 8;
+        int4v re[NPF], ce[NPF];
+        bool special = false;
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) { re[u] = tab[buf][pos[u] & 0xffff]; ce[u] = tab[buf][pos[u] >> 16]; }
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const bool valid = (re[u][3] & ce[u][3]) != 0;
+            // both corners of a row are 6 adjacent bytes (BGR BGR): ONE unaligned 8-byte load per source row; in the
+            // LAST frame the load is pulled back so that it never runs past the end of the buffer
+            const int o0 = valid ? re[u][0] + ce[u][0] : 0, o1 = valid ? re[u][1] + ce[u][0] : 0;
+            int c0 = o0, c1 = o1, fl = ce[u][2];
+            if (last) {
+                c0 = min(o0, lim); c1 = min(o1, lim);
+                fl |= ((o0 - c0) << 11) | ((o1 - c1) << 19);              // (bytes * 8) << 8 and << 16
+            }
+            if (P1_ABL & 1) { rq0[u] = c0; rq1[u] = c1; (void)fbase; }
+            else {
+            rq0[u] = *reinterpret_cast<const u64_unaligned*>(fbase + c0);
+            rq1[u] = *reinterpret_cast<const u64_unaligned*>(fbase + c1);
+            }
+            rfl[u] = valid ? fl : -1;
+            special = special || !valid || !(fl & 1);
+        }
+        edge = last || __builtin_amdgcn_ballot_w64(special) != 0;
+    };
+    auto store_tile_as = [&](int buf, auto EDGE) __attribute__((always_inline)) {
+        constexpr bool E = decltype(EDGE)::value;
+        float wy[NPF], wx[NPF];
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            wy[u] = __int_as_float(tab[buf][pos[u] & 0xffff][2]);
+            wx[u] = __int_as_float(tab[buf][pos[u] >> 16][1]);
+        }
 #pragma unroll
         for (int u = 0; u < NPF; ++u) {
             const int e = tid + u * 256;
-            if (e >= NPX) continue;
-            float v[3] = {0.f, 0.f, 0.f};
-            if (rsh[u] >= 0) {
-                const unsigned long long q0 = rq0[u] >> (rpb[u] & 0xff), q1 = rq1[u] >> (rpb[u] >> 8);
-                const unsigned l0 = (unsigned)q0, h0 = (unsigned)(q0 >> 32), l1 = (unsigned)q1, h1 = (unsigned)(q1 >> 32);
-                const bool two = rsh[u] != 0;                 // x1 = x0 + 1 (else the clamped border: x1 = x0)
-                // bytes of a row piece: B0 G0 R0 B1 | G1 R1 . .  ; output order R, G, B
-                const float a00[3] = {(float)((l0 >> 16) & 0xff), (float)((l0 >> 8) & 0xff), (float)(l0 & 0xff)};
-                const float a01[3] = {(float)((h0 >> 8) & 0xff), (float)(h0 & 0xff), (float)(l0 >> 24)};
-                const float a10[3] = {(float)((l1 >> 16) & 0xff), (float)((l1 >> 8) & 0xff), (float)(l1 & 0xff)};
-                const float a11[3] = {(float)((h1 >> 8) & 0xff), (float)(h1 & 0xff), (float)(l1 >> 24)};
+            float v[3];
+            const unsigned long long q0 = E ? rq0[u] >> ((rfl[u] >> 8) & 0xff) : rq0[u];
+            const unsigned long long q1 = E ? rq1[u] >> ((rfl[u] >> 16) & 0xff) : rq1[u];
+            const unsigned l0 = (unsigned)q0, h0 = (unsigned)(q0 >> 32), l1 = (unsigned)q1, h1 = (unsigned)(q1 >> 32);
+            const bool two = !E || (rfl[u] & 1) != 0;     // x1 = x0 + 1 (else the clamped border: x1 = x0)
+            // bytes of a row piece: B0 G0 R0 B1 | G1 R1 . .  ; output order R, G, B
+            const float a00[3] = {(float)((l0 >> 16) & 0xff), (float)((l0 >> 8) & 0xff), (float)(l0 & 0xff)};
+            const float a01[3] = {(float)((h0 >> 8) & 0xff), (float)(h0 & 0xff), (float)(l0 >> 24)};
+            const float a10[3] = {(float)((l1 >> 16) & 0xff), (float)((l1 >> 8) & 0xff), (float)(l1 & 0xff)};
+            const float a11[3] = {(float)((h1 >> 8) & 0xff), (float)(h1 & 0xff), (float)(l1 >> 24)};
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float sv = bilerp(a00[c], two ? a01[c] : a00[c], a10[c], two ? a11[c] : a10[c], rwx[u], rwy[u]);
-                    v[c] = (sv - 127.5f) * 0.0078125f;
-                }
+            for (int c = 0; c < 3; ++c) {
+                const float sv = bilerp(a00[c], two ? a01[c] : a00[c], a10[c], two ? a11[c] : a10[c], wx[u], wy[u]);
+                v[c] = (!E || rfl[u] >= 0) && !(P1_ABL & 4) ? (sv - 127.5f) * 0.0078125f : 0.f;
             }
             xin[e * 3 + 0] = v[0]; xin[e * 3 + 1] = v[1]; xin[e * 3 + 2] = v[2];
         }
     };
+    auto store_tile = [&](int buf) __attribute__((always_inline)) {
+        if (edge) store_tile_as(buf, std::true_type{});
+        else store_tile_as(buf, std::false_type{});
+    };
 
-    if (item0 < nitems) {
-        load_tile(item0);
-        store_tile();
-    }
     float4v bias_r[3], slope_r[3];
+    bool mono = true;        // every PReLU slope >= 0: bias + PReLU is non-decreasing and commutes with the max pool
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
         bias_r[g] = *reinterpret_cast<const float4v*>(a.bias + g * 4);
         slope_r[g] = *reinterpret_cast<const float4v*>(a.slope + g * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mono = mono && slope_r[g][e] >= 0.f;
+    }
+    if (item0 < nitems) {
+        make_tables(item0, 0);
+        __syncthreads();
+        load_tile(item0, 0);
+        if (RPB > 1 && item0 + 1 < nitems) make_tables(item0 + 1, 1);
+        store_tile(0);
     }
     __syncthreads();
 
@@ -163,7 +232,8 @@ __global__ __launch_bounds__(256) void pnet_conv1_kernel(P1Args a) {
         const int ry = rem / a.regions_x, rx = rem - ry * a.regions_x;
         const int y0 = ry * TH, x0 = rx * P1_TW;
         const bool more = rr + 1 < RPB && item + 1 < nitems;
-        if (more) load_tile(item + 1);                   // global loads fly under this tile's MFMAs
+        const int nbuf = (rr + 1) & 1;
+        if (more) load_tile(item + 1, nbuf);             // global loads fly under this tile's MFMAs
 
         float4v acc[RPW][3];
 #pragma unroll
@@ -186,6 +256,8 @@ __global__ __launch_bounds__(256) void pnet_conv1_kernel(P1Args a) {
                         static_for<3>([&](auto G) {
                             constexpr int g = decltype(G)::value;
                             constexpr int c = (kh * 9 + q) * 3 + g;          // 3k + g, k = (kh*3 + kw)*3 + channel = kh*9 + q
+                            if (P1_ABL & 2) { if (g == 0) asm volatile("" :: "v"(xv[q])); }
+                            else
                             acc[r][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[c / 16], xv[q], acc[r][g], 4, c % 16, 0);
                         });
                     }
@@ -195,57 +267,108 @@ __global__ __launch_bounds__(256) void pnet_conv1_kernel(P1Args a) {
 
         // ---- epilogue: bias + PReLU, 2x2/s2 ceil-mode max pool (rows in registers, columns by one lane exchange)
         const int xcol = x0 + lane;
+        const bool interior = y0 + TH <= a.Ho && x0 + P1_TW <= a.Wo;       // block-uniform: no pixel of the tile is outside
+        auto put = [&](const float4v (&pv)[3], int py, int px) __attribute__((always_inline)) {
+            const int64_t pix = ((int64_t)n * a.Hp + py) * a.Wp + px;
+            float* o = a.y + pix * 12;
 #pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            const int yrow = y0 + wave * RPW + r;
-            const bool inside = yrow < a.Ho && xcol < a.Wo;
+            for (int g = 0; g < 3; ++g) *reinterpret_cast<float4v*>(o + g * 4) = pv[g];
+            if (a.y_split) {
+                // split-f16 copy for the fused conv2/conv3 kernel: [hi ch0-7 | hi ch8-15 | lo ch0-7 | lo ch8-15],
+                // channels 10..15 zero
+                half8 hi[2], lo[2];
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                float4v v = acc[r][g] + bias_r[g];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope_r[g][e];
-                acc[r][g] = inside ? v : float4v{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                for (int c = 0; c < 16; ++c) {
+                    const float x = c < 10 ? pv[c >> 2][c & 3] : 0.f;
+                    const half_t h = (half_t)x;
+                    hi[c >> 3][c & 7] = h;
+                    lo[c >> 3][c & 7] = (half_t)(x - (float)h);
+                }
+                unsigned char* o2 = a.y_split + pix * 64;
+                *reinterpret_cast<half8*>(o2) = hi[0];
+                *reinterpret_cast<half8*>(o2 + 16) = hi[1];
+                *reinterpret_cast<half8*>(o2 + 32) = lo[0];
+                *reinterpret_cast<half8*>(o2 + 48) = lo[1];
             }
-        }
+        };
+        if (mono) {
+            // pool the raw accumulators first (a quarter of the bias / PReLU work), then pack the wave's two pooled rows
+            // into even / odd lanes so that the rest of the epilogue runs with every lane on a pooled pixel
+            if (!interior) {
 #pragma unroll
-        for (int rp = 0; rp < RPW / 2; ++rp) {
-            float4v pv[3];
+                for (int r = 0; r < RPW; ++r) {
+                    const bool inside = y0 + wave * RPW + r < a.Ho && xcol < a.Wo;
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float m = fmaxf(acc[2 * rp][g][e], acc[2 * rp + 1][g][e]);
-                    pv[g][e] = fmaxf(m, __shfl_xor(m, 1, 64));
+                    for (int g = 0; g < 3; ++g)
+                        acc[r][g] = inside ? acc[r][g] : float4v{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                 }
             }
-            const int py = (y0 + wave * RPW + 2 * rp) >> 1, px = xcol >> 1;
-            if ((lane & 1) == 0 && py < a.Hp && px < a.Wp) {
-                const int64_t pix = ((int64_t)n * a.Hp + py) * a.Wp + px;
-                float* o = a.y + pix * 12;
+            float4v pv[RPW / 2][3];
 #pragma unroll
-                for (int g = 0; g < 3; ++g) *reinterpret_cast<float4v*>(o + g * 4) = pv[g];
-                if (a.y_split) {
-                    // split-f16 copy for the fused conv2/conv3 kernel: [hi ch0-7 | hi ch8-15 | lo ch0-7 | lo ch8-15],
-                    // channels 10..15 zero
-                    half8 hi[2], lo[2];
+            for (int rp = 0; rp < RPW / 2; ++rp)
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) {
-                        const float x = c < 10 ? pv[c >> 2][c & 3] : 0.f;
-                        const half_t h = (half_t)x;
-                        hi[c >> 3][c & 7] = h;
-                        lo[c >> 3][c & 7] = (half_t)(x - (float)h);
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float m = vmax(acc[2 * rp][g][e], acc[2 * rp + 1][g][e]);
+                        pv[rp][g][e] = vmax(m, dpp_xor1(m));
                     }
-                    unsigned char* o2 = a.y_split + pix * 64;
-                    *reinterpret_cast<half8*>(o2) = hi[0];
-                    *reinterpret_cast<half8*>(o2 + 16) = hi[1];
-                    *reinterpret_cast<half8*>(o2 + 32) = lo[0];
-                    *reinterpret_cast<half8*>(o2 + 48) = lo[1];
+            float4v q[3];
+            int py = (y0 + wave * RPW) >> 1;
+            bool writer = (lane & 1) == 0;
+            if constexpr (RPW == 4) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = dpp_shr1(pv[1][g][e]);           // odd lane 2j+1 <- second pooled row, pixel j
+                        q[g][e] = (lane & 1) ? t : pv[0][g][e];
+                    }
+                py += lane & 1;
+                writer = true;
+            } else {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) q[g] = pv[0][g];
+            }
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                q[g] += bias_r[g];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q[g][e] = q[g][e] > 0.f ? q[g][e] : q[g][e] * slope_r[g][e];
+            }
+            const int px = (x0 >> 1) + (lane >> 1);
+            if (writer && py < a.Hp && px < a.Wp) put(q, py, px);
+        } else {
+            // a negative slope makes PReLU non-monotonic: activate every pixel, then pool
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const bool inside = y0 + wave * RPW + r < a.Ho && xcol < a.Wo;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    float4v v = acc[r][g] + bias_r[g];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope_r[g][e];
+                    acc[r][g] = inside ? v : float4v{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                 }
+            }
+#pragma unroll
+            for (int rp = 0; rp < RPW / 2; ++rp) {
+                float4v pv[3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float m = vmax(acc[2 * rp][g][e], acc[2 * rp + 1][g][e]);
+                        pv[g][e] = vmax(m, dpp_xor1(m));
+                    }
+                const int py = (y0 + wave * RPW + 2 * rp) >> 1, px = xcol >> 1;
+                if ((lane & 1) == 0 && py < a.Hp && px < a.Wp) put(pv, py, px);
             }
         }
         if (more) {
-            __syncthreads();                 // every wave is done reading this tile
-            store_tile();
+            __syncthreads();                 // every wave is done reading this tile and the tables of the next one's loads
+            store_tile(nbuf);
+            if (rr + 2 < RPB && item + 2 < nitems) make_tables(item + 2, rr & 1);
             __syncthreads();
         }
     }

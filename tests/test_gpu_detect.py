@@ -231,3 +231,50 @@ def test_fused_split_f16_pnet_equals_f32_pnet():
     refined = int(fused.refined_cells[0])
     print(f"\nfused P-Net: max |head - f32 head| = {worst:.2e}; kept {kept} of {total} cells; re-evaluated exactly: {refined // 2} per pass")
     assert kept >= 100 and refined >= kept
+
+
+@pytest.mark.parametrize("negative_slopes", [False, True])
+def test_pnet_conv1_kernel_vs_oracle_and_16x16x4_form(negative_slopes):
+    """P-Net conv1 (+ pyramid resize, PReLU, 2x2 ceil pool) runs as its own 4x4x1-MFMA kernel (csrc/pnet_conv1.hip).
+    Against the oracle's resize + conv + PReLU + pool in f32 (tolerance: summation order), and bit for bit against the
+    16x16x4-MFMA form of the same layer (layer id 3: same fma chain) - pooled map and split-f16 copy, on levels whose
+    sizes exercise ragged tiles, one-row / one-column maps and the last-frame pull-back.  With some NEGATIVE PReLU
+    slopes the kernel may not pool before it activates (the max pool only commutes with a non-decreasing function)."""
+    import math
+    from facerecognition_infrenceengine_amd import _lib, weights
+    from facerecognition_infrenceengine_amd.mtcnn import MTCNNHIP, pyramid_scales
+    st = weights.synth_mtcnn_states(seed=99)
+    if negative_slopes:
+        st[0]["prelu1.weight"] = st[0]["prelu1.weight"] * torch.tensor([1, -1, 1, -0.5, 1, 1, -2, 1, 1, -1.0])
+    d = MTCNNHIP(*st, device="cuda:0")
+    p1, lib = d.p1, d.lib
+    g = torch.Generator(device="cuda").manual_seed(5)
+    w1, b1, s1 = (st[0][k].float() for k in ("conv1.weight", "conv1.bias", "prelu1.weight"))
+    for (N, H, W) in [(2, 120, 160), (1, 250, 333), (3, 37, 53), (1, 480, 640)]:
+        frames = torch.randint(0, 256, (N, H, W, 3), generator=g, device="cuda", dtype=torch.uint8)
+        for sc in pyramid_scales(H, W):
+            hs, ws = int(math.ceil(H * sc)), int(math.ceil(W * sc))
+            if hs < 3 or ws < 3:
+                continue
+            h, w = p1.out_hw(hs, ws)
+            outs = []
+            for layer in (0, 3):
+                y = torch.full((N, h, w, 12), float("nan"), dtype=torch.float32, device="cuda")
+                xs = torch.full((N, h, w, 64), 0x7f, dtype=torch.uint8, device="cuda")
+                rc = lib.fr_dconv_mfma_f32(layer, None, _lib.ptr(p1.w), _lib.ptr(p1.b), _lib.ptr(p1.slope), _lib.ptr(y),
+                                           N, hs, ws, None, None, _lib.ptr(frames), H, W, None, 0, _lib.ptr(xs),
+                                           _lib.stream_ptr())
+                assert rc == 0
+                outs.append((y, xs))
+            torch.cuda.synchronize()
+            assert torch.equal(outs[0][0].view(torch.int32), outs[1][0].view(torch.int32)), (N, H, W, hs, ws)
+            assert torch.equal(outs[0][1], outs[1][1]), (N, H, W, hs, ws)
+            # oracle: level image -> conv -> PReLU -> ceil-mode 2x2 pool (first frame)
+            rgb = frames[0].cpu().numpy()[:, :, ::-1].astype(np.float32)
+            x = odetect._to_net(odetect.resize_bilinear(rgb, hs, ws))
+            c = torch.nn.functional.conv2d(x, w1, b1)
+            c = torch.where(c > 0, c, c * s1[None, :, None, None])
+            want = torch.nn.functional.max_pool2d(c, 2, 2, ceil_mode=True)[0].permute(1, 2, 0).numpy()
+            got = outs[0][0][0, :, :, :10].cpu().numpy()
+            np.testing.assert_allclose(got, want, atol=3e-5, rtol=1e-5)
+            assert float(outs[0][0][..., 10:].abs().max()) == 0.0

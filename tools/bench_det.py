@@ -1,11 +1,18 @@
-"""Dev tool: detector-only time per 64x1080p batch (single stream: kernel times add up)."""
-import sys, os
+"""Dev tool: detector-only time per 64x1080p batch, with P-Net conv1 as the 4x4x1-MFMA kernel (layer 0) and as the
+16x16x4 form (layer 3), one stream (kernel times add up) and the default two level streams."""
+import sys, os, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("FR_DET_ONE_STREAM", "1")
+if len(sys.argv) < 2:
+    for one in ("1", "0"):
+        for layer in ("3", "0", "3", "0"):
+            env = dict(os.environ, FR_DET_ONE_STREAM=one)
+            subprocess.run([sys.executable, __file__, layer], env=env, check=True)
+    sys.exit(0)
 import torch, bench, warnings
 from facerecognition_infrenceengine_amd import FaceAnalysis
 warnings.simplefilter("ignore")
 app = FaceAnalysis(name="synthetic", arch="r100", cap_o=4).prepare(ctx_id=0)
+app.det.p1.layer = int(sys.argv[1])
 frames = bench.synth_frames(64, 1080, 1920, 0, torch.device("cuda:0"))
 for _ in range(3):
     app.det.detect_batch(frames)
@@ -15,4 +22,4 @@ e0.record()
 for _ in range(10):
     app.det.detect_batch(frames)
 e1.record(); torch.cuda.synchronize()
-print("detect ms", round(e0.elapsed_time(e1) / 10, 3))
+print("one_stream", os.environ.get("FR_DET_ONE_STREAM"), "p1 layer", sys.argv[1], "detect ms", round(e0.elapsed_time(e1) / 10, 3))
