@@ -40,7 +40,10 @@ class FaceAnalysis:
     """Same constructor / prepare / get surface as insightface.app.FaceAnalysis.
 
     ``name`` selects a model directory ``<root>/models/<name>/`` holding ``arcface_<arch>.pt|.safetensors``
-    and ``mtcnn_{pnet,rnet,onet}.pt`` state dicts (public PyTorch naming, see weights.py).  When the
+    and ``mtcnn_{pnet,rnet,onet}.pt`` state dicts (public PyTorch naming, see weights.py).  A recognition network
+    shipped as ONNX - the ``w600k_r50.onnx`` of the reference's own buffalo_l pack - is read too (onnx_import.py: the
+    first ``*.onnx`` of the directory whose graph is an ArcFace IResNet; ``arch`` then follows the file).  The pack's
+    detector is SCRFD, not MTCNN: without ``mtcnn_*.pt`` files the detector falls back to synthetic weights.  When the
     directory is absent the engine falls back to SEEDED SYNTHETIC weights and says so loudly:
     the pipeline is then numerically exact w.r.t. its oracle but recognises nothing.
     ``providers`` is accepted for signature compatibility and ignored (HIP only).
@@ -65,10 +68,21 @@ class FaceAnalysis:
             ps = [os.path.join(d, f"mtcnn_{n}{ext}") for n in ("pnet", "rnet", "onet")]
             if det is None and all(os.path.exists(q) for q in ps):
                 det = tuple(weights.load_state(q) for q in ps)
+        if rec is None and os.path.isdir(d):              # insightface packs ship the recognition network as ONNX
+            from .onnx_import import iresnet_state_from_onnx
+            for fn in sorted(os.listdir(d)):
+                if fn.endswith(".onnx"):
+                    try:
+                        st, arch = iresnet_state_from_onnx(os.path.join(d, fn))
+                    except (ValueError, IndexError, KeyError):
+                        continue                           # the pack's detector / landmark / attribute models
+                    rec, self.arch = {k: torch.from_numpy(v) for k, v in st.items()}, arch
+                    break
         self.synthetic = rec is None or det is None
         if self.synthetic:
-            warnings.warn(f"model pack '{self.name}' not found under {d}: using SEEDED SYNTHETIC weights "
-                          f"(numerically exact pipeline, meaningless identities)")
+            missing = " and ".join(w for w, x in (("recognition", rec), ("MTCNN detector", det)) if x is None)
+            warnings.warn(f"model pack '{self.name}' under {d}: no {missing} weights found: using SEEDED SYNTHETIC "
+                          f"weights for them (numerically exact pipeline, meaningless identities)")
         return (rec or weights.synth_iresnet_state(self.arch), det or weights.synth_mtcnn_states())
 
     def prepare(self, ctx_id=0, det_thresh=None, det_size=None):

@@ -29,9 +29,17 @@ FC_SPLITK = 28
 SMALL_BATCH = int(os.environ.get("FR_SMALL_BATCH", "48"))      # measured crossover: 32 faces 2.7 vs 3.3 ms, 64 faces 4.6 vs 3.7 ms
 
 
-def _bn_fold(st, prefix):
-    s = st[prefix + ".weight"].double() / torch.sqrt(st[prefix + ".running_var"].double() + BN_EPS)
-    t = st[prefix + ".bias"].double() - st[prefix + ".running_mean"].double() * s
+def _bn_fold(st, prefix, n, conv=None):
+    """(scale, shift) of an inference BatchNorm; the identity when the state dict has no such BN (an exporter folded
+    it into the conv before it: onnx_import.py).  ``conv``: name of the conv feeding it - its bias, if any, joins
+    the shift."""
+    if prefix + ".weight" in st:
+        s = st[prefix + ".weight"].double() / torch.sqrt(st[prefix + ".running_var"].double() + BN_EPS)
+        t = st[prefix + ".bias"].double() - st[prefix + ".running_mean"].double() * s
+    else:
+        s, t = torch.ones(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+    if conv is not None and conv + ".bias" in st:
+        t = t + s * st[conv + ".bias"].double()
     return s, t
 
 
@@ -82,10 +90,10 @@ class IResNetHIP:
         self.arch = arch
         self.max_chunk = max_chunk
         layers = IRESNET_LAYERS[arch]
-        st = {k: v.detach().to("cpu") for k, v in state.items()}
+        st = {k: torch.as_tensor(v).detach().to("cpu") for k, v in state.items()}
         dev = self.device
         # stem: conv1 + bn1 + prelu, packed K = 16 taps x 8 channels
-        s, t = _bn_fold(st, "bn1")
+        s, t = _bn_fold(st, "bn1", 64, conv="conv1")
         w = st["conv1.weight"].double() * s[:, None, None, None]
         wp = torch.zeros(64, 16, 8, dtype=torch.float64)
         wp[:, :9, :3] = w.permute(0, 2, 3, 1).reshape(64, 9, 3)
@@ -96,9 +104,9 @@ class IResNetHIP:
             for bi in range(n):
                 p = f"layer{li}.{bi}"
                 stride = 2 if bi == 0 else 1
-                s1, t1 = _bn_fold(st, p + ".bn1")
-                s2, t2 = _bn_fold(st, p + ".bn2")
-                s3, t3 = _bn_fold(st, p + ".bn3")
+                s1, t1 = _bn_fold(st, p + ".bn1", cin)
+                s2, t2 = _bn_fold(st, p + ".bn2", cout, conv=p + ".conv1")
+                s3, t3 = _bn_fold(st, p + ".bn3", cout, conv=p + ".conv2")
                 w1 = st[p + ".conv1.weight"].double()
                 w1f = w1 * s2[:, None, None, None] * s1[None, :, None, None]
                 tap = (w1 * t1[None, :, None, None]).sum(1) * s2[:, None, None]      # [co,kh,kw]
@@ -116,14 +124,14 @@ class IResNetHIP:
                     c2.w32 = w2f.permute(0, 2, 3, 1).reshape(cout, -1).to(torch.float32)
                 sc = None
                 if bi == 0:
-                    sd, td = _bn_fold(st, p + ".downsample.1")
+                    sd, td = _bn_fold(st, p + ".downsample.1", cout, conv=p + ".downsample.0")
                     wd = st[p + ".downsample.0.weight"].double() * sd[:, None, None, None]
                     sc = _Conv(_pack_w(wd), td, None, cin, cout, 1, stride, 0, 0, dev)
                 self.blocks.append((c1, c2, sc))
                 cin = cout
         # tail
-        sb, tb = _bn_fold(st, "bn2")
-        sf, tf = _bn_fold(st, "features")
+        sb, tb = _bn_fold(st, "bn2", 512)
+        sf, tf = _bn_fold(st, "features", 512)
         W = st["fc.weight"].double().reshape(512, 512, 49)                   # [o, c, hw]
         bias = sf * (st["fc.bias"].double() + (W * tb[None, :, None]).sum((1, 2))) + tf
         Wf = (W * sb[None, :, None] * sf[:, None, None]).permute(0, 2, 1).reshape(512, 49 * 512)   # NHWC K order

@@ -116,7 +116,12 @@ def synth_mtcnn_states(seed=4321, face_logit_bias=None):
 
 
 def load_state(path):
-    """Load a real checkpoint (torch ``.pt``/``.pth`` state dict or ``.safetensors``)."""
+    """Load a real checkpoint (torch ``.pt``/``.pth`` state dict, ``.safetensors``, or an ArcFace IResNet ``.onnx``
+    such as the ``w600k_r50.onnx`` of the reference's buffalo_l pack: onnx_import.py)."""
+    if str(path).endswith(".onnx"):
+        from .onnx_import import iresnet_state_from_onnx
+        st, _ = iresnet_state_from_onnx(str(path))
+        return {k: torch.from_numpy(v) for k, v in st.items()}
     if str(path).endswith(".safetensors"):
         from safetensors.torch import load_file
         return load_file(str(path))

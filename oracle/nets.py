@@ -20,7 +20,14 @@ def _t(state, key):
     return v if isinstance(v, torch.Tensor) else torch.as_tensor(v)
 
 
+def _b(state, key):
+    """optional conv bias (present when an exporter folded the following BatchNorm into the conv)"""
+    return _t(state, key) if key in state else None
+
+
 def _bn(x, state, prefix):
+    if prefix + ".weight" not in state:        # folded into the conv before it by an exporter (onnx_import.py)
+        return x
     return F.batch_norm(x, _t(state, prefix + ".running_mean"), _t(state, prefix + ".running_var"),
                         _t(state, prefix + ".weight"), _t(state, prefix + ".bias"),
                         training=False, eps=BN_EPS)
@@ -41,7 +48,7 @@ def iresnet_forward(state, x, layers, taps=None):
     Returns the un-normalised 512-d embedding.  ``taps`` (optional dict) receives
     named intermediate activations (NCHW) for layer-by-layer kernel checks.
     """
-    x = F.conv2d(x, _t(state, "conv1.weight"), None, stride=1, padding=1)
+    x = F.conv2d(x, _t(state, "conv1.weight"), _b(state, "conv1.bias"), stride=1, padding=1)
     x = _prelu(_bn(x, state, "bn1"), state, "prelu.weight")
     if taps is not None:
         taps["stem"] = x
@@ -50,14 +57,14 @@ def iresnet_forward(state, x, layers, taps=None):
             p = f"layer{li}.{bi}"
             stride = 2 if bi == 0 else 1
             out = _bn(x, state, p + ".bn1")
-            out = F.conv2d(out, _t(state, p + ".conv1.weight"), None, stride=1, padding=1)
+            out = F.conv2d(out, _t(state, p + ".conv1.weight"), _b(state, p + ".conv1.bias"), stride=1, padding=1)
             out = _prelu(_bn(out, state, p + ".bn2"), state, p + ".prelu.weight")
             if taps is not None and bi == 0:
                 taps[p + ".mid"] = out
-            out = F.conv2d(out, _t(state, p + ".conv2.weight"), None, stride=stride, padding=1)
+            out = F.conv2d(out, _t(state, p + ".conv2.weight"), _b(state, p + ".conv2.bias"), stride=stride, padding=1)
             out = _bn(out, state, p + ".bn3")
             if bi == 0:
-                sc = F.conv2d(x, _t(state, p + ".downsample.0.weight"), None, stride=stride)
+                sc = F.conv2d(x, _t(state, p + ".downsample.0.weight"), _b(state, p + ".downsample.0.bias"), stride=stride)
                 sc = _bn(sc, state, p + ".downsample.1")
             else:
                 sc = x
@@ -67,9 +74,10 @@ def iresnet_forward(state, x, layers, taps=None):
     x = _bn(x, state, "bn2")
     x = torch.flatten(x, 1)            # NCHW order: c*49 + h*7 + w (dropout = identity)
     x = F.linear(x, _t(state, "fc.weight"), _t(state, "fc.bias"))
-    x = F.batch_norm(x, _t(state, "features.running_mean"), _t(state, "features.running_var"),
-                     _t(state, "features.weight"), _t(state, "features.bias"),
-                     training=False, eps=BN_EPS)
+    if "features.weight" in state:
+        x = F.batch_norm(x, _t(state, "features.running_mean"), _t(state, "features.running_var"),
+                         _t(state, "features.weight"), _t(state, "features.bias"),
+                         training=False, eps=BN_EPS)
     return x
 
 

@@ -272,6 +272,39 @@ def test_model_pack_on_disk_round_trips_through_load_state(app, tmp_path):
         assert np.array_equal(x.embedding, y.embedding) and np.array_equal(x.bbox, y.bbox)
 
 
+def test_model_pack_with_an_onnx_recognition_network(tmp_path):
+    """The reference's pack ships its ArcFace network as ONNX (buffalo_l/w600k_r50.onnx, infrenceServer.py:412-416).  A
+    pack holding an exporter-style r50 graph (BatchNorms folded into the convs) next to a file that is not an IResNet
+    must come up as r50 with that network: embeddings of the same crops equal those of an engine built from the
+    original state dict within f16 folding noise, and match the fp32 oracle."""
+    from facerecognition_infrenceengine_amd import FaceAnalysis, weights
+    from facerecognition_infrenceengine_amd.iresnet import IResNetHIP
+    from oracle import nets
+    from tests.helpers import onnx_write as ow
+    d = tmp_path / "models" / "buffalo_like"
+    d.mkdir(parents=True)
+    st = weights.synth_iresnet_state("r50", seed=11)
+    ow.write_iresnet_onnx(d / "w600k_r50.onnx", {k: v.numpy() for k, v in st.items()}, "r50", fold_bn=True)
+    (d / "det_10g.onnx").write_bytes(ow._vi(1, 7) + ow._ld(7, ow._ld(11, ow._ld(1, b"x"))))     # parses, is no IResNet
+    for n, s in zip(("pnet", "rnet", "onet"), weights.synth_mtcnn_states()):
+        torch.save(s, str(d / f"mtcnn_{n}.pt"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        b = FaceAnalysis(name="buffalo_like", root=str(tmp_path)).prepare(ctx_id=0)
+    assert b.arch == "r50" and b.synthetic is False
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(4, 3, 112, 112, generator=g).clamp(-1, 1)
+    xp = torch.zeros(4, 112, 112, 8, dtype=torch.float16)
+    xp[..., :3] = x.permute(0, 2, 3, 1).to(torch.float16)
+    xd = xp.cuda()
+    emb_pack, _ = b.rec.forward(xd)
+    emb_orig, _ = IResNetHIP(st, "r50", "cuda:0").forward(xd)
+    want = nets.iresnet_forward(st, xp[..., :3].float().permute(0, 3, 1, 2), nets.IRESNET_LAYERS["r50"])
+    cos = torch.nn.functional.cosine_similarity
+    assert (1 - cos(emb_pack.cpu(), emb_orig.cpu())).max().item() < 1e-4
+    assert (1 - cos(emb_pack.cpu(), want)).max().item() < 1e-3
+
+
 def test_processor_threads_share_one_engine_while_the_gallery_syncs(app):
     """FaceRecognitionProcessor.recognize from 3 threads on ONE engine while another thread keeps force_sync()ing a
     store whose membership changes: detection runs under the engine lock, a stale company view is re-fetched and
