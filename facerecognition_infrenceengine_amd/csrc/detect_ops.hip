@@ -329,6 +329,7 @@ extern "C" int fr_box_refine(float* boxes, const float* aux, int naux, const int
 // Zero-padded crop of the (1-based inclusive) box trunc(b), bilinear to size x size, RGB normalised,
 // written as 4-channel pixels (RGB0) so that the first R/O-Net conv reads 16-byte pixels.
 // One block per candidate slot; invalid slots (>= count, or empty boxes) are zero-filled.
+typedef unsigned long long u64_unaligned_t __attribute__((aligned(1)));
 __global__ __launch_bounds__(256) void crop_resize_norm(const uint8_t* __restrict__ frames, int H, int W,
                                                         const float* __restrict__ boxes,
                                                         const int32_t* __restrict__ counts, int cap, int size,
@@ -342,6 +343,7 @@ __global__ __launch_bounds__(256) void crop_resize_norm(const uint8_t* __restric
     const bool valid = i < counts[f] && tw > 0 && th > 0;
     const uint8_t* fr = frames + (int64_t)f * H * W * 3;
     const float ry = (float)th / (float)size, rx = (float)tw / (float)size;
+    const int lim = f == (int)(gridDim.x / cap) - 1 ? H * W * 3 - 8 : 0x7fffffff;
     for (int t = threadIdx.x; t < size * size; t += 256) {
         const int oy = t / size, ox = t - oy * size;
         float v[3] = {0.f, 0.f, 0.f};
@@ -350,15 +352,30 @@ __global__ __launch_bounds__(256) void crop_resize_norm(const uint8_t* __restric
             const int ys[2] = {y1 - 1 + ly.i0, y1 - 1 + ly.i1};
             const int xs[2] = {x1 - 1 + lx.i0, x1 - 1 + lx.i1};
             float p[2][2][3];
+            // both corners of a source row are 6 adjacent bytes (BGR BGR): ONE unaligned 8-byte load per row when the
+            // two columns are neighbours inside the frame (all but the crop's clamped last column and crops that
+            // stick out of the frame); in the LAST frame the load is pulled back so it never runs past the buffer
+            const bool pair = xs[1] == xs[0] + 1 && xs[0] >= 0 && xs[1] < W;
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 2; ++a) {
+                const bool row_in = ys[a] >= 0 && ys[a] < H;
+                if (pair && row_in) {
+                    const int off = (ys[a] * W + xs[0]) * 3;
+                    const int c = min(off, lim);
+                    const unsigned long long q = *reinterpret_cast<const u64_unaligned_t*>(fr + c) >> ((off - c) * 8);
+                    const unsigned lo = (unsigned)q, hi = (unsigned)(q >> 32);
+                    p[a][0][0] = (float)((lo >> 16) & 0xff); p[a][0][1] = (float)((lo >> 8) & 0xff); p[a][0][2] = (float)(lo & 0xff);
+                    p[a][1][0] = (float)((hi >> 8) & 0xff); p[a][1][1] = (float)(hi & 0xff); p[a][1][2] = (float)(lo >> 24);
+                } else {
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const bool in = ys[a] >= 0 && ys[a] < H && xs[c] >= 0 && xs[c] < W;
-                    const uint8_t* px = fr + ((int64_t)(in ? ys[a] : 0) * W + (in ? xs[c] : 0)) * 3;
+                    for (int c = 0; c < 2; ++c) {
+                        const bool in = row_in && xs[c] >= 0 && xs[c] < W;
+                        const uint8_t* px = fr + ((int64_t)(in ? ys[a] : 0) * W + (in ? xs[c] : 0)) * 3;
 #pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) p[a][c][ch] = in ? (float)px[2 - ch] : 0.f;
+                        for (int ch = 0; ch < 3; ++ch) p[a][c][ch] = in ? (float)px[2 - ch] : 0.f;
+                    }
                 }
+            }
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch)
                 v[ch] = (bilerp(p[0][0][ch], p[0][1][ch], p[1][0][ch], p[1][1][ch], lx.w, ly.w) - 127.5f) * 0.0078125f;
