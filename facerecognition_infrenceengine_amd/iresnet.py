@@ -27,6 +27,9 @@ BN_EPS = 1e-5
 FC_SPLITK = 28
 # up to this many faces the 3x3 convs run split along K (see IResNetHIP._small_batch_splitk)
 SMALL_BATCH = int(os.environ.get("FR_SMALL_BATCH", "48"))      # measured crossover: 32 faces 2.7 vs 3.3 ms, 64 faces 4.6 vs 3.7 ms
+# up to this many faces (single frames) every K slice is at most 3 K steps long: a slice's steps are dependent HBM
+# round trips (the weights are cold: 130 MB per forward), so a launch takes ~1.2 us per step + ~3 us
+LOW_BATCH = int(os.environ.get("FR_LOW_BATCH", "8"))
 
 
 def _bn_fold(st, prefix, n, conv=None):
@@ -204,11 +207,16 @@ class IResNetHIP:
         """Small batches (single frames: a handful of faces) leave most CUs without an output tile and every block
         runs its whole K loop alone (measured: 16 faces 3.06 ms, 29 us per conv launch).  Their 3x3 convs are cut
         along K into slices that run side by side, followed by ``fr_conv_splitk_epilogue``.  The slice count
-        depends on the layer only (not on B), so results do not depend on the batch size inside this mode."""
+        depends on the layer and on the MODE only (B <= LOW_BATCH: slices of 3 K steps; B <= SMALL_BATCH: of 9), so
+        results do not depend on the batch size inside a mode (between modes they differ by f32 summation order)."""
         if B > SMALL_BATCH or c.k != 3 or c.cin % 64:
             return 1
         nk = 9 * c.cin // 64
-        return max(1, min(8, nk // 9))
+        if nk < 18:                  # Cin = 64 (the 112x112 / 56x56 layers): one pass
+            return 1
+        if B <= LOW_BATCH:
+            return -(-nk // 3)
+        return min(8, nk // 9)
 
     def _conv(self, x, c, B, H, W, residual=None, partial=None, splitk=1, y=None):
         Ho = (H + 2 * c.pad - c.k) // c.stride + 1

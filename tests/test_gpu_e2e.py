@@ -144,7 +144,13 @@ def test_slot_path_equals_compact_path(app):
     assert cnt == a["counts"]
     cap = b["bbox"].shape[1]
     rows = torch.tensor([f * cap + j for f, n in enumerate(cnt) for j in range(n)], device="cuda")
-    assert torch.equal(b["embedding"][rows], a["embedding"])
+    from facerecognition_infrenceengine_amd.iresnet import LOW_BATCH, SMALL_BATCH
+    mode = lambda B: 0 if B <= LOW_BATCH else (1 if B <= SMALL_BATCH else 2)
+    if mode(sum(cnt)) == mode(len(cnt) * cap):          # same split-K mode of the embed network: the same bits
+        assert torch.equal(b["embedding"][rows], a["embedding"])
+    else:
+        cos = torch.nn.functional.cosine_similarity(b["embedding"][rows], a["embedding"])
+        assert float((1 - cos).max()) < 1e-5
     assert torch.equal(b["bbox"].reshape(-1, 4)[rows], a["bbox"])
 
 
@@ -231,22 +237,30 @@ def test_frame_ingest_ring_feeds_the_pipeline(app):
 
 
 def test_graph_replay_equals_eager(app):
-    """enable_graphs(): the captured slot pipeline gives the same Face lists as the eager path, call after call."""
+    """enable_graphs(): the captured slot pipeline gives the same Face lists as the eager path, call after call.
+    The embed network sums its small-batch split-K slices in a batch-size MODE (<= 8 faces, <= 48, more: iresnet.py):
+    with cap_o = 4 the eager call (its faces) and the captured one (4 slots) run in the same mode and must agree bit
+    for bit; with the default 16 slots the modes differ and the embeddings agree to f16 rounding noise."""
     from make_golden import synth_frame
     frames = [synth_frame(240, 320, s) for s in (4, 5, 6)]
-    eager = [app.get(f) for f in frames]
-    try:
-        app.enable_graphs(True)
-        for _ in range(2):
-            for f, want in zip(frames, eager):
-                got = app.get(f)
-                assert len(got) == len(want) and len(got) >= 1
-                for a, b in zip(want, got):
-                    assert np.array_equal(a.bbox, b.bbox) and np.array_equal(a.kps, b.kps)
-                    assert a.det_score == b.det_score and np.array_equal(a.embedding, b.embedding)
-                    assert np.array_equal(a.normed_embedding, b.normed_embedding)
-    finally:
-        app.enable_graphs(False)
+    for eng, exact in ((app.clone_with(cap_o=4), True), (app, False)):
+        eager = [eng.get(f) for f in frames]
+        try:
+            eng.enable_graphs(True)
+            for _ in range(2):
+                for f, want in zip(frames, eager):
+                    got = eng.get(f)
+                    assert len(got) == len(want) and len(got) >= 1
+                    for a, b in zip(want, got):
+                        assert np.array_equal(a.bbox, b.bbox) and np.array_equal(a.kps, b.kps)
+                        assert a.det_score == b.det_score
+                        if exact:
+                            assert np.array_equal(a.embedding, b.embedding)
+                            assert np.array_equal(a.normed_embedding, b.normed_embedding)
+                        else:
+                            assert 1.0 - float(a.normed_embedding @ b.normed_embedding) < 1e-5
+        finally:
+            eng.enable_graphs(False)
 
 
 def test_model_pack_on_disk_round_trips_through_load_state(app, tmp_path):
