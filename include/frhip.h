@@ -211,6 +211,9 @@ int fr_dconv_f32(const float* x, const float* w, const float* bias, const float*
  * 12 channels, R/O-Net conv1 read 4).  Layer 0 takes `frames` (u8 BGR [B,FH,FW,3]) instead of x: the
  * pyramid level (H x W) is resized on the fly inside the tile load, with the same arithmetic as
  * fr_pyramid_resize_norm.  Blocks walk several tiles, prefetching the next tile into registers.
+ * Layer 0 runs as its own kernel on v_mfma_f32_4x4x1 with a broadcast weight operand (pnet_conv1.hip: K = 27
+ * exactly, one pixel per lane; needs slope != NULL); layer 3 is the same layer on the 16x16x4 form with the same
+ * arguments and bit-identical outputs (same fma chain), kept for the A/B and the equality test.
  * counts / cap (R-/O-Net layers, optional): the batch is B / cap frames x cap crop slots and slot j of frame f
  * holds a candidate iff j < counts[f] (device i32); blocks that cover empty slots only do no work and leave those
  * outputs unwritten.  NULL: every image is computed.
