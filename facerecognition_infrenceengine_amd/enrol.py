@@ -29,7 +29,13 @@ class Enroller:
         self.device = face_analysis.device
 
     def process_image(self, image):
-        """trainingServer.py:216-247: normed embedding of the largest face, or None."""
+        """trainingServer.py:216-247: normed embedding of the largest face, or None.  ``image``: a BGR uint8 array, or
+        the encoded bytes the reference reads from GridFS (``:219-221``: decoded here, None when they do not decode)."""
+        if isinstance(image, (bytes, bytearray, memoryview)):
+            from .ingest import decode_image
+            image = decode_image(image)
+            if image is None:
+                return None
         faces = self.app.get(image)
         if not faces:
             return None

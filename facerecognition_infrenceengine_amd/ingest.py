@@ -7,10 +7,27 @@ page-locked ring slots (``host_buffer``), ``upload`` starts an asynchronous copy
 dedicated HIP copy stream and returns an event; the detector stream waits for that event only, so the copy of
 batch i+1 runs under the kernels of batch i.  The HUD overlay stays on the CPU (out of scope).
 """
+import io
+
 import numpy as np
 import torch
 
 from . import _lib
+
+
+def decode_image(data):
+    """Encoded image bytes (JPEG / PNG ...) -> ``uint8 [H,W,3]`` BGR, or None when the bytes do not decode: the
+    ``cv2.imdecode(np.frombuffer(blob, np.uint8), cv2.IMREAD_COLOR)`` of the enrolment worker
+    (/root/reference/trainingServer.py:219-224), with Pillow standing in for OpenCV (absent from the image).  Host
+    side by design (decode stays on the CPU); JPEG decoders differ in their IDCT rounding, so
+    pixel values can differ from OpenCV's by a unit - the lossless formats decode identically."""
+    try:
+        from PIL import Image
+        with Image.open(io.BytesIO(bytes(data))) as im:
+            rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
+    except Exception:                        # the reference logs "Failed to decode" and skips the image
+        return None
+    return np.ascontiguousarray(rgb[:, :, ::-1])
 
 
 class FrameIngest:
@@ -28,6 +45,15 @@ class FrameIngest:
     def host_buffer(self, slot):
         """NumPy view of the slot's pinned buffer: the decoder / capture thread writes frames here."""
         return self._host[slot % self.depth].numpy()
+
+    def decode_into(self, slot, index, data):
+        """Decode image bytes straight into frame ``index`` of the slot's pinned buffer (no intermediate pageable
+        copy).  False when the bytes do not decode or the picture is not the ring's H x W."""
+        img = decode_image(data)
+        if img is None or img.shape != self.shape[1:]:
+            return False
+        self.host_buffer(slot)[index] = img
+        return True
 
     def upload(self, slot):
         """Start the H2D copy of the slot; returns (device frames, event that fires when they have landed).

@@ -199,3 +199,27 @@ def test_camera_manager_batches_sources_and_keeps_reference_queue_semantics():
     assert cm.stats["frames"] >= 3 and cm.stats["largest_batch"] >= 2 and all(n <= 3 for n, _ in proc.batches)
     assert len(seen) >= 3 and {s for s, _ in seen} <= {0, 1, 2}
     assert all(getattr(c, "released", False) for c in caps.values())
+
+
+def test_decode_image_is_the_imdecode_of_the_enrolment_path():
+    """ingest.decode_image: encoded bytes -> BGR uint8 (trainingServer.py:219-221).  PNG round trip is lossless and
+    must be exact incl. the channel order; JPEG decodes to within the codec's error; garbage gives None."""
+    import io
+    from PIL import Image
+    from facerecognition_infrenceengine_amd.ingest import decode_image
+    rng = np.random.default_rng(0)
+    bgr = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(bgr[:, :, ::-1]).save(buf, format="PNG")
+    got = decode_image(buf.getvalue())
+    assert got.dtype == np.uint8 and got.flags["C_CONTIGUOUS"] and np.array_equal(got, bgr)
+    smooth = np.clip(np.add.outer(np.arange(64), np.arange(80))[:, :, None] + np.array([0, 40, 90]), 0, 255).astype(np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(smooth[:, :, ::-1]).save(buf, format="JPEG", quality=95)
+    got = decode_image(buf.getvalue())
+    assert got.shape == smooth.shape and np.abs(got.astype(int) - smooth.astype(int)).max() <= 6
+    grey = io.BytesIO()
+    Image.fromarray(smooth[:, :, 0]).save(grey, format="PNG")                 # IMREAD_COLOR: grey -> 3 equal channels
+    g3 = decode_image(grey.getvalue())
+    assert g3.shape == smooth.shape and np.array_equal(g3[:, :, 0], g3[:, :, 2])
+    assert decode_image(b"not an image") is None
