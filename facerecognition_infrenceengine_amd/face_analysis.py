@@ -114,8 +114,9 @@ class FaceAnalysis:
         with self._lock, torch.cuda.device(self.device):
             boxes, scores, kps, counts = self.det.detect_batch(frames)
             cap = boxes.shape[1]
+            kps = kps.contiguous()
             crops = torch.empty((N * cap, 112, 112, 8), dtype=torch.float16, device=self.device)
-            self.lib.fr_warp_affine_5pt_slots(_lib.ptr(frames), N, H, W, _lib.ptr(kps.contiguous()), _lib.ptr(counts), cap,
+            self.lib.fr_warp_affine_5pt_slots(_lib.ptr(frames), N, H, W, _lib.ptr(kps), _lib.ptr(counts), cap,
                                               112, _lib.ptr(crops), _lib.stream_ptr())
             valid = (torch.arange(cap, device=self.device)[None, :] < counts[:, None]).reshape(-1).nonzero().squeeze(1)
             if valid.numel() == 0:
@@ -169,7 +170,7 @@ class FaceAnalysis:
         out["embedding"], out["normed_embedding"] = emb, normed
         return out
 
-    def detect_embed_slots(self, frames, det_stream=None, ready_event=None):
+    def detect_embed_slots(self, frames, det_stream=None, ready_event=None, compact_embed=False):
         """Sync-free form for streaming/serving: every frame owns ``cap_o`` face slots.
 
         frames: uint8 [N,H,W,3] BGR on the device.  Returns device tensors only (no host sync):
@@ -181,7 +182,11 @@ class FaceAnalysis:
         current stream, so batch i+1's cascade (latency-bound, leaves CU slots idle) runs beside batch i's embed
         convs (MFMA-bound).  The caller guarantees ``frames`` is complete before this call is made (it is when the
         frames were produced on ``det_stream`` or synchronised earlier) or passes ``ready_event`` (e.g. the event of
-        ``FrameIngest.upload``), which the detector's stream waits for."""
+        ``FrameIngest.upload``), which the detector's stream waits for.
+
+        compact_embed: embed only the slots that hold a face (ONE host sync on the face counts after the detector),
+        the outputs keep the slot layout.  For callers that read the results on the host anyway (the camera batcher):
+        8 cameras x 16 slots with a face or two each would otherwise pay for 128 embeddings."""
         if self.det is None:
             raise _lib.FrError("FaceAnalysis.prepare() has not been called")
         N, H, W, _ = frames.shape
@@ -199,6 +204,26 @@ class FaceAnalysis:
             for t in (boxes, scores, kps, counts):
                 t.record_stream(cur)
         cap = boxes.shape[1]
+        if compact_embed:
+            cnt = counts.cpu()                                            # the extra sync
+            sel = (torch.arange(cap)[None, :] < cnt[:, None]).reshape(-1).nonzero().squeeze(1).to(self.device)
+            emb = torch.zeros((N * cap, 512), dtype=torch.float32, device=self.device)
+            emb[:, 0] = 1.0                                               # empty slots: a unit vector, never NaN downstream
+            normed = emb.clone()
+            if sel.numel():
+                with torch.cuda.device(self.device):
+                    F = sel.numel()
+                    crops = torch.empty((F, 112, 112, 8), dtype=torch.float16, device=self.device)
+                    # named, not inline: a temporary dies as soon as its pointer is taken and the next temporary
+                    # may be handed the same block before the kernel has read it
+                    kps_sel = kps.reshape(-1, 5, 2)[sel].contiguous()
+                    frame_idx = (sel // cap).to(torch.int32)
+                    self.lib.fr_warp_affine_5pt(_lib.ptr(frames), N, H, W, _lib.ptr(kps_sel), _lib.ptr(frame_idx), None,
+                                                F, 112, _lib.ptr(crops), None, None, _lib.stream_ptr())
+                    e, nm = self.rec.forward(crops)
+                    emb[sel], normed[sel] = e, nm
+            return {"counts": counts, "bbox": boxes, "kps": kps, "det_score": scores, "embedding": emb,
+                    "normed_embedding": normed}
         with torch.cuda.device(self.device):
             crops = torch.empty((N * cap, 112, 112, 8), dtype=torch.float16, device=self.device)
             self.lib.fr_warp_affine_5pt_slots(_lib.ptr(frames), N, H, W, _lib.ptr(kps), _lib.ptr(counts), cap, 112,

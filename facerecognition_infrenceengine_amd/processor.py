@@ -301,7 +301,7 @@ class FaceRecognitionProcessor:
             for i, a in enumerate(arr):
                 host[i] = a
             dev, ready = ring.upload(turn)
-            r = det.detect_embed_slots(dev, ready_event=ready)
+            r = det.detect_embed_slots(dev, ready_event=ready, compact_embed=True)      # results go to the host anyway
             ring.release(turn)
         matcher, metadata, idx, score = _match_fresh(self.embedding_manager, company_id, matcher, metadata,
                                                      r["normed_embedding"])

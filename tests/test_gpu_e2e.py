@@ -236,6 +236,30 @@ def test_frame_ingest_ring_feeds_the_pipeline(app):
             assert torch.equal(w[k].reshape(valid.numel(), -1)[valid], g[k].reshape(valid.numel(), -1)[valid]), k
 
 
+def test_slot_path_with_compact_embed(app):
+    """detect_embed_slots(compact_embed=True) embeds only the slots that hold a face (one sync on the counts) and keeps
+    the slot layout: detector outputs identical, embeddings of the valid slots equal to the all-slots run (same bits in
+    the same split-K mode, f16 rounding noise otherwise), empty slots finite."""
+    from make_golden import synth_frame
+    from facerecognition_infrenceengine_amd.iresnet import LOW_BATCH, SMALL_BATCH
+    frs = torch.from_numpy(np.ascontiguousarray(np.stack([synth_frame(240, 320, s) for s in (4, 5, 6, 7)]))).cuda()
+    a = app.detect_embed_slots(frs)
+    b = app.detect_embed_slots(frs, compact_embed=True)
+    assert torch.equal(a["counts"], b["counts"])
+    cap = a["bbox"].shape[1]
+    cnt = a["counts"].cpu()
+    valid = (torch.arange(cap)[None, :] < cnt[:, None]).reshape(-1).cuda()
+    for k in ("bbox", "kps", "det_score"):               # empty slots hold whatever the allocator left there
+        assert torch.equal(a[k].reshape(valid.numel(), -1)[valid], b[k].reshape(valid.numel(), -1)[valid]), k
+    assert int(valid.sum()) >= 2 and bool(torch.isfinite(b["normed_embedding"]).all())
+    mode = lambda B: 0 if B <= LOW_BATCH else (1 if B <= SMALL_BATCH else 2)
+    if mode(int(valid.sum())) == mode(valid.numel()):
+        assert torch.equal(a["embedding"][valid], b["embedding"][valid])
+    else:
+        cos = torch.nn.functional.cosine_similarity(a["normed_embedding"][valid], b["normed_embedding"][valid])
+        assert float((1 - cos).max()) < 1e-5
+
+
 def test_graph_replay_equals_eager(app):
     """enable_graphs(): the captured slot pipeline gives the same Face lists as the eager path, call after call.
     The embed network sums its small-batch split-K slices in a batch-size MODE (<= 8 faces, <= 48, more: iresnet.py):
@@ -449,8 +473,9 @@ def test_camera_batcher_equals_per_frame_recognition(app):
         for x, y in zip(a, b):
             assert np.array_equal(x["bbox"], y["bbox"]) and x["person_id"] == y["person_id"]
             assert x["det_score"] == y["det_score"]
-            # the embed net picks its kernels by batch size (split-K below 48 faces): scores agree to f16-conv rounding
-            assert abs(float(x["recognition_score"]) - float(y["recognition_score"])) < 1e-4
+            # the embed net picks its kernels by batch-size mode (<= 8, <= 48 faces, more): the per-frame calls and the
+            # batch (its faces together) may run in different modes; scores then agree to f16-conv rounding
+            assert abs(float(x["recognition_score"]) - float(y["recognition_score"])) < 5e-4
     outs = [cm.result_queue.get_nowait() for _ in range(4)]
     assert [s for s, _ in outs] == [0, 1, 2, 3] and all(o.shape == (240, 320, 3) for _, o in outs)
     assert proc.recognize_batch(frames[:2], "nobody") is None          # unknown company: no gallery, frames untouched
