@@ -363,7 +363,8 @@ def main():
     sb, ss, sk, sc = app.det.detect_batch(batches[0])
     ev[1].record()
     crops0 = torch.empty((FRAMES * FACES_PER_FRAME, 112, 112, 8), dtype=torch.float16, device=device)
-    app.lib.fr_warp_affine_5pt_slots(_lib.ptr(batches[0]), FRAMES, H, W, _lib.ptr(sk.contiguous()), _lib.ptr(sc),
+    sk = sk.contiguous()
+    app.lib.fr_warp_affine_5pt_slots(_lib.ptr(batches[0]), FRAMES, H, W, _lib.ptr(sk), _lib.ptr(sc),
                                      FACES_PER_FRAME, 112, _lib.ptr(crops0), _lib.stream_ptr())
     emb0, nrm0 = app.rec.forward(crops0)
     ev[2].record()
