@@ -135,7 +135,10 @@ def load():
 
 
 def ptr(t):
-    """Device pointer of a torch tensor (or None)."""
+    """Device pointer of a torch tensor (or None).  The pointer does not keep the tensor alive: pass NAMED tensors.
+    ``ptr(x[sel].contiguous())`` written inline frees the temporary as soon as the pointer is taken, and a second
+    temporary built for the next argument of the same call can be handed the same block - its producer kernel is
+    then queued BEFORE the consumer and overwrites the data (found the hard way: face_analysis.py compact_embed)."""
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
