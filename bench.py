@@ -410,6 +410,25 @@ def main():
                 "launches_per_step": calls, "avg_launch_us": round(secs / calls * 1e6, 2),
                 "algorithmic_gflop_per_launch": round(flops / calls / 1e9, 3)}
 
+    # ---- yardstick (outside the timed region): the vendor library's plain f16 GEMM of the dominant conv's own shape on
+    # this box - M = pixels of the batch's 14x14 maps, N = 256 couts, K = 9 * 256 - no gather, no epilogue
+    if world == 1 and not args.no_side and dom.startswith("conv_halo_kernel<2, 13, 256") and not dom.endswith(", true, 8, 0>"):
+        gm_, gn_, gk_ = FRAMES * FACES_PER_FRAME * 196, 256, 2304
+        ga = torch.randn((gm_, gk_), device=device, dtype=torch.float16)
+        gb = torch.randn((gn_, gk_), device=device, dtype=torch.float16)
+        for _ in range(3):
+            torch.matmul(ga, gb.t())
+        ge0, ge1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ge0.record()
+        for _ in range(20):
+            torch.matmul(ga, gb.t())
+        ge1.record()
+        torch.cuda.synchronize()
+        gus = ge0.elapsed_time(ge1) / 20 * 1e3
+        roofline["library_gemm_same_shape"] = {"what": f"torch.matmul f16 {gm_}x{gn_}x{gk_} (hipBLASLt), no gather / epilogue",
+                                               "us": round(gus, 2), "tflops": round(2.0 * gm_ * gn_ * gk_ / gus / 1e6, 1)}
+        del ga, gb
+
     # ---- side measurements for the other half of BASELINE's metric (rank 0, one GPU, default workload only)
     side = {}
     if world == 1 and args.workload == "C2" and not args.no_side:
