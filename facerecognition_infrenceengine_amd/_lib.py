@@ -24,6 +24,10 @@ class ConvArgs(C.Structure):
                 ("Ho", C.c_int), ("Wo", C.c_int), ("bias_mode", C.c_int), ("splitk", C.c_int)]
 
 
+class ConvStep(C.Structure):
+    _fields_ = [("kind", C.c_int), ("args", ConvArgs)]
+
+
 class ConvF8Args(C.Structure):
     _fields_ = [("x8", C.c_void_p), ("w8", C.c_void_p), ("y16", C.c_void_p), ("y8", C.c_void_p),
                 ("oscale", C.c_void_p), ("bias", C.c_void_p), ("slope", C.c_void_p), ("residual", C.c_void_p),
@@ -56,6 +60,7 @@ SIGNATURES = {
     "fr_cosine_matrix_f32": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "fr_mean_rows_f32": (_I, [_P, _I, _I, _P, _P]),
     "fr_conv_nhwc_f16": (_I, [C.POINTER(ConvArgs), _P]),
+    "fr_conv_sequence": (_I, [C.POINTER(ConvStep), _I, _P]),
     "fr_conv_nhwc_f8": (_I, [C.POINTER(ConvF8Args), _P]),
     "fr_quantize_f16_f8": (_I, [_P, _P, _L, _F, _P]),
     "fr_conv_splitk_epilogue": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P]),

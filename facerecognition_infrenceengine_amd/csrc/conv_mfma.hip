@@ -505,6 +505,30 @@ extern "C" int fr_conv_splitk_epilogue(const float* partial, int splitk, int M, 
     return FR_OK;
 }
 
+extern "C" int fr_conv_sequence(const fr_conv_step* steps, int nsteps, fr_stream_t stream) {
+    FR_REQUIRE(steps && nsteps > 0, "fr_conv_sequence: no steps");
+    for (int i = 0; i < nsteps; ++i) {
+        const fr_conv_step& st = steps[i];
+        int rc;
+        if (st.kind == 0) {
+            rc = fr_conv_nhwc_f16(&st.args, stream);
+        } else if (st.kind == 1) {
+            const fr_conv_args& a = st.args;
+            FR_REQUIRE(a.splitk > 1 && a.out_f32_partial && a.y, "fr_conv_sequence: step %d: split-K step without splitk / partial / y", i);
+            fr_conv_args p = a;                         // the partials launch: no epilogue operands
+            p.y = nullptr; p.bias = nullptr; p.slope = nullptr; p.residual = nullptr; p.bias_mode = 0;
+            rc = fr_conv_nhwc_f16(&p, stream);
+            if (rc == FR_OK)
+                rc = fr_conv_splitk_epilogue(a.out_f32_partial, a.splitk, a.B * a.Ho * a.Wo, a.Cout, a.Ho, a.Wo, a.bias,
+                                             a.bias_mode, a.slope, a.residual, a.y, stream);
+        } else {
+            FR_REQUIRE(false, "fr_conv_sequence: step %d: unknown kind %d", i, st.kind);
+        }
+        if (rc != FR_OK) return rc;
+    }
+    return FR_OK;
+}
+
 // ---- FC tail: reduce split-K partials + bias -> embedding; L2-normalise (one wave per face)
 __global__ void fc_reduce_l2norm(const float* __restrict__ partial, int splitk, int B, int dim,
                                  const float* __restrict__ bias, float* __restrict__ emb, float* __restrict__ normed) {

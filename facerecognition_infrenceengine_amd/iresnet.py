@@ -141,6 +141,7 @@ class IResNetHIP:
         self.fc_w = Wf.to(torch.float16).contiguous().to(dev)
         self.fc_bias = bias.to(torch.float32).contiguous().to(dev)
         self.flops_per_face = self._count_flops()
+        self._plans = {}             # (B, stream) -> prepared fr_conv_sequence of the single-frame forward
         self.profile = None          # bench.py: list collecting (kernel variant, flops, ev0, ev1) per conv launch
         self.fp8 = False             # enable_fp8(): eligible body convs run on the fp8 matrix cores
         self._calib = None
@@ -272,8 +273,74 @@ class IResNetHIP:
                 self._forward_chunk(x[b0:b1], emb[b0:b1], normed[b0:b1], taps)
         return emb, normed
 
+    # ---- single frames: the whole conv stack as ONE C call over persistent buffers
+    def _plan(self, B):
+        """Up to LOW_BATCH faces the forward is ~200 launches of a few microseconds each and the Python / ctypes work
+        per launch (argument structs, allocations, stream look-ups) is what the GPU waits for.  The same launch
+        sequence as ``_forward_chunk`` is laid out once per (B, stream) - four rotating activation buffers, one
+        split-K scratch - and replayed by ``fr_conv_sequence``.  Per stream: launches on one stream run in order, so
+        they can share the buffers; another stream gets its own."""
+        key = (B, torch.cuda.current_stream(self.device).cuda_stream)
+        plan = self._plans.get(key)
+        if plan is not None:
+            return plan
+        if len(self._plans) >= 16:       # never evicted (a captured HIP graph may hold a plan's buffers): past this, launch by launch
+            return None
+        dev = self.device
+        bufs = [torch.empty(B * 112 * 112 * 64, dtype=torch.float16, device=dev) for _ in range(4)]
+        steps, part_floats = [], 0
+
+        def view(buf, Ho, Wo, c):
+            return buf[:B * Ho * Wo * c].view(B, Ho, Wo, c)
+
+        def add(c, x, y, H, W, residual=None):
+            nonlocal part_floats
+            Ho = (H + 2 * c.pad - c.k) // c.stride + 1
+            Wo = (W + 2 * c.pad - c.k) // c.stride + 1
+            sk = self._small_batch_splitk(c, B)
+            if sk > 1:
+                part_floats = max(part_floats, sk * B * Ho * Wo * c.cout)
+            steps.append((1 if sk > 1 else 0, c, x, y, residual, H, W, Ho, Wo, sk))
+            return Ho, Wo
+
+        free = list(bufs)
+        h = free.pop()
+        H, W = add(self.stem, None, h, 112, 112)                      # x (the crops) is patched in per call
+        hc = 64
+        for c1, c2, sc in self.blocks:
+            mid = free.pop()
+            add(c1, view(h, H, W, hc), mid, H, W)
+            short = view(h, H, W, hc)
+            s_buf = None
+            if sc is not None:
+                s_buf = free.pop()
+                Ho, Wo = add(sc, view(h, H, W, hc), s_buf, H, W)
+                short = view(s_buf, Ho, Wo, sc.cout)
+            out = free.pop()
+            Ho, Wo = add(c2, view(mid, H, W, c1.cout), out, H, W, residual=short)
+            free += [b for b in (h, mid, s_buf) if b is not None]
+            h, H, W, hc = out, Ho, Wo, c2.cout
+        partial = torch.empty(max(part_floats, 1), dtype=torch.float32, device=dev)
+        arr = (_lib.ConvStep * len(steps))()
+        for st, (kind, c, x, y, residual, Hi, Wi, Ho, Wo, sk) in zip(arr, steps):
+            st.kind = kind
+            st.args = _lib.ConvArgs(_lib.ptr(x), _lib.ptr(c.w), _lib.ptr(y), _lib.ptr(c.bias), _lib.ptr(c.slope),
+                                    _lib.ptr(residual), _lib.ptr(partial) if kind else None, B, Hi, Wi, c.cin, c.cout,
+                                    c.k, c.k, c.stride, c.pad, Ho, Wo, c.bias_mode, sk)
+        plan = self._plans[key] = (arr, len(steps), view(h, H, W, hc), bufs, partial)
+        return plan
+
     def _forward_chunk(self, x, emb, normed, taps):
         B = x.shape[0]
+        plan = None
+        if B <= LOW_BATCH and taps is None and self.profile is None and self._calib is None and not self.fp8:
+            plan = self._plan(B)
+        if plan is not None:
+            arr, n, h, _, _ = plan
+            arr[0].args.x = x.data_ptr()
+            self.lib.fr_conv_sequence(arr, n, _lib.stream_ptr())
+            self._fc(h, B, emb, normed)
+            return
         h, H, W = self._conv(x, self.stem, B, 112, 112)
         if taps is not None:
             taps["stem"] = h
@@ -317,6 +384,9 @@ class IResNetHIP:
                 taps[f"_block{len(taps)}"] = None
         if taps is not None:
             taps["final"] = h
+        self._fc(h, B, emb, normed)
+
+    def _fc(self, h, B, emb, normed):
         # FC as a 1x1 conv over a 1x1 image with Cin = 25088, split-K -> f32 partials
         partial = torch.empty((FC_SPLITK, B, 512), dtype=torch.float32, device=self.device)
         fc = _FC(self.fc_w)

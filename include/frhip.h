@@ -163,6 +163,16 @@ int fr_quantize_f16_f8(const void* x16, void* out8, int64_t n, float mul, fr_str
 int fr_conv_splitk_epilogue(const float* partial, int splitk, int M, int Cout, int Ho, int Wo,
                             const float* bias, int bias_mode, const float* slope, const void* residual,
                             void* y, fr_stream_t stream);
+/* A prepared run of convs in ONE call (single frames are launch-bound from an interpreted host: ~100 convs of a few
+ * microseconds each).  Step kind 0: fr_conv_nhwc_f16(args).  Kind 1: the small-batch split-K form of the conv that
+ * `args` describes as a whole (x, w, y, bias, bias_mode, slope, residual, splitk > 1, out_f32_partial = scratch of
+ * splitk * M * Cout floats): the partials launch followed by fr_conv_splitk_epilogue into args.y.  Same kernels, same
+ * order, same bits as the individual calls; stops at the first failing step. */
+typedef struct {
+    int kind;
+    fr_conv_args args;
+} fr_conv_step;
+int fr_conv_sequence(const fr_conv_step* steps, int nsteps, fr_stream_t stream);
 /* FC tail: sum split-K partials + bias -> embedding f32 [B,dim]; then
  * normed_embedding = embedding / ||embedding|| (Face.normed_embedding, infrenceServer.py:532) */
 int fr_fc_reduce_l2norm(const float* partial, int splitk, int B, int dim, const float* bias,

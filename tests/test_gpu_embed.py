@@ -126,6 +126,38 @@ def test_r100_batch_independence(r100):
     assert torch.equal(e_all[3:4], e_one)
 
 
+def test_prepared_sequence_equals_launch_by_launch(r100, monkeypatch):
+    """Up to 8 faces the conv stack runs as ONE fr_conv_sequence call over persistent buffers (iresnet._plan).  Same
+    kernels, same order: the embeddings must equal the launch-by-launch forward bit for bit, call after call (buffer
+    reuse), for every batch size of the mode, and on a second stream (its own buffers)."""
+    from facerecognition_infrenceengine_amd import iresnet
+    g = torch.Generator().manual_seed(9)
+    for B in (1, 3, 8):
+        xa = nchw_to_nhwc8(torch.rand((B, 3, 112, 112), generator=g) * 2 - 1)
+        with monkeypatch.context() as m:
+            m.setattr(iresnet, "LOW_BATCH", 0)                  # no plan: launch by launch (slice counts follow LOW_BATCH too)
+            m.setattr(iresnet.IResNetHIP, "_small_batch_splitk", lambda self, c, Bn, f=iresnet.IResNetHIP._small_batch_splitk:
+                      _sk_low(c))
+            want, _ = r100.forward(xa)
+        for _ in range(2):
+            got, gotn = r100.forward(xa)
+            assert torch.equal(got, want)
+        s2 = torch.cuda.Stream()
+        s2.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s2):
+            got2, _ = r100.forward(xa)
+        s2.synchronize()
+        assert torch.equal(got2, want)
+    assert len(r100._plans) >= 4
+
+
+def _sk_low(c):
+    """the slice count of the <= LOW_BATCH mode (iresnet._small_batch_splitk), whatever LOW_BATCH is patched to"""
+    if c.k != 3 or c.cin % 64 or 9 * c.cin // 64 < 18:
+        return 1
+    return -(-(9 * c.cin // 64) // 3)
+
+
 def test_r50_variant_vs_oracle():
     """buffalo_l's recogniser is an IResNet-50 (SURVEY.md F2): the same kernels run it (arch='r50')."""
     from facerecognition_infrenceengine_amd import weights
