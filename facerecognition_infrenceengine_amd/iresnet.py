@@ -17,6 +17,7 @@ Folding (inference BN):  s = gamma / sqrt(var + eps),  t = beta - mean * s.
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -142,6 +143,7 @@ class IResNetHIP:
         self.fc_bias = bias.to(torch.float32).contiguous().to(dev)
         self.flops_per_face = self._count_flops()
         self._plans = {}             # (B, stream) -> prepared fr_conv_sequence of the single-frame forward
+        self._plan_lock = threading.Lock()       # engines cloned with clone_with() share this network across threads
         self.profile = None          # bench.py: list collecting (kernel variant, flops, ev0, ev1) per conv launch
         self.fp8 = False             # enable_fp8(): eligible body convs run on the fp8 matrix cores
         self._calib = None
@@ -334,12 +336,14 @@ class IResNetHIP:
         B = x.shape[0]
         plan = None
         if B <= LOW_BATCH and taps is None and self.profile is None and self._calib is None and not self.fp8:
-            plan = self._plan(B)
+            with self._plan_lock:
+                plan = self._plan(B)
         if plan is not None:
             arr, n, h, _, _ = plan
-            arr[0].args.x = x.data_ptr()
-            self.lib.fr_conv_sequence(arr, n, _lib.stream_ptr())
-            self._fc(h, B, emb, normed)
+            with self._plan_lock:                # the input pointer is patched into the shared step array
+                arr[0].args.x = x.data_ptr()
+                self.lib.fr_conv_sequence(arr, n, _lib.stream_ptr())
+                self._fc(h, B, emb, normed)
             return
         h, H, W = self._conv(x, self.stem, B, 112, 112)
         if taps is not None:
