@@ -143,6 +143,7 @@ class IResNetHIP:
         self.fc_bias = bias.to(torch.float32).contiguous().to(dev)
         self.flops_per_face = self._count_flops()
         self._plans = {}             # (B, stream) -> prepared fr_conv_sequence of the single-frame forward
+        self._plan_bufs = {}         # stream -> (4 activation buffers, split-K scratch) shared by that stream's plans
         self._plan_lock = threading.Lock()       # engines cloned with clone_with() share this network across threads
         self.profile = None          # bench.py: list collecting (kernel variant, flops, ev0, ev1) per conv launch
         self.fp8 = False             # enable_fp8(): eligible body convs run on the fp8 matrix cores
@@ -276,20 +277,38 @@ class IResNetHIP:
         return emb, normed
 
     # ---- single frames: the whole conv stack as ONE C call over persistent buffers
+    def _plan_partial_floats(self, B):
+        """split-K scratch of the largest conv of a B-face forward (floats)"""
+        n, hw = 1, 112
+        for c1, c2, sc in self.blocks:
+            n = max(n, self._small_batch_splitk(c1, B) * B * hw * hw * c1.cout)
+            ho = hw // c2.stride
+            n = max(n, self._small_batch_splitk(c2, B) * B * ho * ho * c2.cout)
+            hw = ho
+        return n
+
     def _plan(self, B):
         """Up to LOW_BATCH faces the forward is ~200 launches of a few microseconds each and the Python / ctypes work
         per launch (argument structs, allocations, stream look-ups) is what the GPU waits for.  The same launch
         sequence as ``_forward_chunk`` is laid out once per (B, stream) - four rotating activation buffers, one
         split-K scratch - and replayed by ``fr_conv_sequence``.  Per stream: launches on one stream run in order, so
         they can share the buffers; another stream gets its own."""
-        key = (B, torch.cuda.current_stream(self.device).cuda_stream)
+        sid = torch.cuda.current_stream(self.device).cuda_stream
+        key = (B, sid)
         plan = self._plans.get(key)
         if plan is not None:
             return plan
-        if len(self._plans) >= 16:       # never evicted (a captured HIP graph may hold a plan's buffers): past this, launch by launch
-            return None
         dev = self.device
-        bufs = [torch.empty(B * 112 * 112 * 64, dtype=torch.float16, device=dev) for _ in range(4)]
+        # buffers are per STREAM and sized for LOW_BATCH faces: every batch size of the mode lays its steps over them
+        # (never freed: a captured HIP graph may hold them); past 8 streams, launch by launch
+        shared = self._plan_bufs.get(sid)
+        if shared is None:
+            if len(self._plan_bufs) >= 8:
+                return None
+            shared = self._plan_bufs[sid] = (
+                [torch.empty(LOW_BATCH * 112 * 112 * 64, dtype=torch.float16, device=dev) for _ in range(4)],
+                torch.empty(self._plan_partial_floats(LOW_BATCH), dtype=torch.float32, device=dev))
+        bufs, partial = shared
         steps, part_floats = [], 0
 
         def view(buf, Ho, Wo, c):
@@ -322,7 +341,7 @@ class IResNetHIP:
             Ho, Wo = add(c2, view(mid, H, W, c1.cout), out, H, W, residual=short)
             free += [b for b in (h, mid, s_buf) if b is not None]
             h, H, W, hc = out, Ho, Wo, c2.cout
-        partial = torch.empty(max(part_floats, 1), dtype=torch.float32, device=dev)
+        assert part_floats <= partial.numel()
         arr = (_lib.ConvStep * len(steps))()
         for st, (kind, c, x, y, residual, Hi, Wi, Ho, Wo, sk) in zip(arr, steps):
             st.kind = kind
