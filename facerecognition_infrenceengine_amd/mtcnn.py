@@ -132,6 +132,7 @@ class MTCNNHIP:
         self._sides = {}
         self._tls = threading.local()      # per-thread launch stream: detect_batch is re-entrant across threads
         self._one_stream = os.environ.get("FR_DET_ONE_STREAM") == "1"      # profiling: per-kernel times add up
+        self._nsides = int(os.environ.get("FR_DET_SIDES", "1"))
         d = self.device
         p, r, o = ({k: v.detach().float().cpu() for k, v in s.items()} for s in (pstate, rstate, ostate))
         self.p1 = _MConv(0, p["conv1.weight"], p["conv1.bias"], p["prelu1.weight"], d)
@@ -261,8 +262,13 @@ class MTCNNHIP:
         return x.reshape(B, 16)
 
     # ---- cascade
-    def detect_batch(self, frames, trace=None):
+    def detect_batch(self, frames, trace=None, level_streams=None):
         """frames: uint8 [N,H,W,3] BGR device tensor (contiguous).
+
+        level_streams: side HIP streams (1 or 2) the pyramid levels 1.. are dealt over; level 0 stays on the caller's
+        stream.  Default 1.  Two were measured: a 64 x 1080p batch ALONE in a fresh process 7.55 -> 7.1 ms (three: the
+        same, four: slower), but nothing inside the bench process (7.9 either way with its dozen other streams) and
+        ~1 % less end-to-end throughput when the detector is overlapped with the embedder - so it stays an option.
 
         Returns device tensors: boxes f32 [N,cap_o,4], scores f32 [N,cap_o], kps f32 [N,cap_o,5,2],
         counts i32 [N] (faces per frame, in descending-score order)."""
@@ -283,13 +289,17 @@ class MTCNNHIP:
             ksz = self.keep_scale
             kb, ks, ka, kc = self._f32(nlev, N, ksz, 4), self._f32(nlev, N, ksz), self._f32(nlev, N, ksz, 4), self._i32(nlev, N)
             # Level 0 holds half of the pyramid's pixels; the remaining levels are small launches that cannot fill
-            # 256 CUs on their own, so they run on a second HIP stream beside level 0 (joined before the NMS).
+            # 256 CUs on their own, so they are dealt round-robin over side HIP streams beside level 0 (joined before
+            # the NMS).
             main = torch.cuda.current_stream()
-            side = self._sides.get(main.cuda_stream)          # one side stream per caller stream: independent
-            if side is None:                                  # pipelines (bench --pipes) do not couple through it
-                side = self._sides[main.cuda_stream] = torch.cuda.Stream(device=self.device)
-            side.wait_stream(main)
+            sides = self._sides.get(main.cuda_stream)         # side streams per caller stream: independent
+            if sides is None:                                 # pipelines (bench --pipes) do not couple through them
+                sides = self._sides[main.cuda_stream] = [torch.cuda.Stream(device=self.device) for _ in range(2)]
+            sides = sides[:max(1, min(2, level_streams if level_streams is not None else self._nsides))]
+            for side in sides:
+                side.wait_stream(main)
             for li, s in enumerate(scales):
+                side = sides[(li - 1) % len(sides)] if li else sides[0]
                 with torch.cuda.stream(main if li == 0 or trace is not None or self._one_stream else side):
                     self._s = _lib.stream_ptr()
                     head, hc, wc = self.pnet_level(frames, s, trace)
@@ -308,7 +318,8 @@ class MTCNNHIP:
                     if trace is not None:
                         trace.setdefault("pnet_head", []).append(head)
                         trace.setdefault("pnet_prob", []).append(prob)
-            main.wait_stream(side)
+            for side in sides:
+                main.wait_stream(side)
             self._s = _lib.stream_ptr()
             if N < 8:
                 self._nms(lb, ls, lr, 4, lc, nlev * N, 1, cs, 0, 0.5, 0, ksz, out=(kb, ks, ka, kc))
