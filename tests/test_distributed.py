@@ -102,6 +102,12 @@ def test_world4_matches_unsharded():
     _run(4, 257, [1, 8, 0, 4])
 
 
+def test_world8_matches_unsharded():
+    """the driver's largest run: 8 ranks, a rank without faces, ragged counts, 5 rows spread over 8 shards"""
+    _run(8, 1001, [3, 0, 8, 1, 5, 2, 7, 4])
+    _run(8, 5, [1, 1, 0, 2, 1, 0, 1, 1])          # three ranks hold an empty gallery shard
+
+
 def test_shard_rows_partition():
     from facerecognition_infrenceengine_amd.distributed import shard_rows
     for n in (0, 1, 7, 10000, 1000003):
