@@ -406,6 +406,7 @@ static void launch_conv(const ConvP& p, hipStream_t s) {
 }
 
 int fr_conv_halo_try(const fr_conv_args* a, hipStream_t s);     // conv_halo.hip
+int fr_conv_stem_try(const fr_conv_args* a, hipStream_t s);     // conv_stem.hip
 
 static bool conv_halo_enabled() { return fr_dbg_int("FR_CONV_HALO", 1) != 0; }   // debug build: FR_CONV_HALO=0 for A/B
 
@@ -444,6 +445,12 @@ extern "C" int fr_conv_nhwc_f16(const fr_conv_args* a, fr_stream_t stream) {
         if (h < 0) return h;
         if (h == 1) {
             FR_CHECK_LAUNCH("conv_halo_kernel");
+            return FR_OK;
+        }
+    }
+    if (small) {                                   // the packed stem has its own kernel (conv_stem.hip)
+        if (fr_conv_stem_try(a, s) == 1) {
+            FR_CHECK_LAUNCH("conv_stem_kernel");
             return FR_OK;
         }
     }

@@ -257,8 +257,8 @@ class IResNetHIP:
                     halo = "conv_halo_kernel<1, 14, 384, 1, 4, false, false, 4, false, 8, 0>"
                 elif H == 112 and c.cin == 64 and c.cout == 64:
                     halo = "conv_halo_kernel<1, 14, 512, 1, 4, false, false, 4, false, 8, 0>"
-            variant = halo or "conv_mfma_kernel<%d, %s, true>" % (2 if c.cout % 128 == 0 else 1,
-                                                                  "true" if c.cin == 8 else "false")
+            variant = halo or ("conv_stem_kernel<112>" if c.cin == 8 else
+                               "conv_mfma_kernel<%d, false, true>" % (2 if c.cout % 128 == 0 else 1))
             kreal = 27 if c.cin == 8 else c.k * c.k * c.cin       # algorithmic K (stem: 3 real channels)
             self.profile.append((variant, 2.0 * B * Ho * Wo * c.cout * kreal, e0, e1))
         else:

@@ -76,6 +76,33 @@ def test_conv_layer_vs_torch(lib, case):
     _conv_case(lib, *case, seed=hash(case) & 0xffff)
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 112, 112), (1, 8, 16), (2, 20, 48)])
+def test_stem_kernel_vs_torch(lib, B, H, W):
+    """The packed stem (f16 [B,H,W,8]: RGB + zeros; weights [64][16 taps][8]) has its own kernel (conv_stem.hip): against
+    torch's fp32 conv of the f16 operands + bias + PReLU, incl. the zero border and sizes other than 112."""
+    from facerecognition_infrenceengine_amd import _lib
+    g = torch.Generator().manual_seed(B * 1000 + W)
+    x = (torch.rand((B, 3, H, W), generator=g) * 2 - 1).to(torch.float16)
+    w = (torch.randn((64, 3, 3, 3), generator=g) * 0.2).to(torch.float16)
+    bias = torch.randn(64, generator=g) * 0.1
+    slope = torch.rand(64, generator=g) * 0.4
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), bias, padding=1)
+    ref = torch.where(ref > 0, ref, ref * slope[None, :, None, None])
+    xp = torch.zeros((B, H, W, 8), dtype=torch.float16)
+    xp[..., :3] = x.permute(0, 2, 3, 1)
+    wp = torch.zeros((64, 16, 8), dtype=torch.float16)
+    wp[:, :9, :3] = w.permute(0, 2, 3, 1).reshape(64, 9, 3)
+    xd, wd, bd, sd = xp.cuda(), wp.reshape(64, 128).contiguous().cuda(), bias.cuda(), slope.cuda()
+    y = torch.full((B, H, W, 64), float("nan"), dtype=torch.float16, device="cuda")
+    a = _lib.ConvArgs(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), _lib.ptr(bd), _lib.ptr(sd), None, None,
+                      B, H, W, 8, 64, 3, 3, 1, 1, H, W, 0, 1)
+    lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert bool(torch.isfinite(got).all())
+    assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 2e-3
+
+
 def test_mfma_layout_integer_exact(lib):
     """A = small integers, asymmetric: catches a transposed / permuted fragment map exactly."""
     from facerecognition_infrenceengine_amd import _lib
