@@ -24,6 +24,7 @@ struct HaloP {
     const float* oscale; unsigned char* y8; float y8_mul;   // F8: acc * oscale[cout] first; optional fp8 copy of the output * y8_mul
     int B, H, W, Cin, Cout, bias_mode;
     int TH, tiles_per_img;      // output rows per tile, H / TH
+    int G;                      // images per tile (1; 4 at 7x7, where TH = H: a tile = G whole images, each with its own halo)
     unsigned xbytes, wbytes;
     unsigned long long* stamps; // diagnostic build only (FR_DBG_STAMPS=<device ptr>): per-wave segment cycle sums
     int stagger;                // diagnostic build only (FR_HALO_STAGGER): start delay of every second block, in 512-cycle units
@@ -119,9 +120,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_halo_kernel(HaloP p) {
     const int ntn = p.Cout / BN;
     const int cout0 = (tile % ntn) * BN;
     const int mt = tile / ntn;
-    const int n = mt / p.tiles_per_img, y0 = (mt - n * p.tiles_per_img) * p.TH;
+    const int n = (mt / p.tiles_per_img) * p.G, y0 = (mt - (mt / p.tiles_per_img) * p.tiles_per_img) * p.TH;   // first image of the tile
     const int HW = p.W + 2;
-    const int nhalo = (p.TH + 2) * HW;
+    const int IH = (p.TH + 2) * HW;                    // halo rows of ONE image's part of the tile
+    const int nhalo = p.G * IH;
+    const int IPX = p.TH * p.W;                        // output pixels of one image's part
 
     __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
     __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
@@ -136,11 +139,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_halo_kernel(HaloP p) {
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
         const int h = (wave * NXI + i) * 8 + lrow;
-        const int hy = h / HW, hx = h - hy * HW;
+        const int gi = h / IH, hr = h - gi * IH;                 // image of the tile, halo row inside its part
+        const int hy = hr / HW, hx = hr - hy * HW;
         const int iy = y0 - 1 + hy, ix = hx - 1;
-        const bool ok = h < nhalo && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const int xch = (lane & 7) ^ ((h - 2 * hy) & 7);
-        xoff[i] = ok ? (unsigned)(((n * p.H + iy) * p.W + ix) * p.Cin * ES + xch * 16) : 0x80000000u;
+        const bool ok = h < nhalo && n + gi < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const int xch = (lane & 7) ^ ((h - 2 * (gi * (p.TH + 2) + hy)) & 7);
+        xoff[i] = ok ? (unsigned)((((n + gi) * p.H + iy) * p.W + ix) * p.Cin * ES + xch * 16) : 0x80000000u;
     }
     unsigned woff[NWI];
     const int K = 9 * p.Cin;
@@ -172,10 +176,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_halo_kernel(HaloP p) {
     for (int j = 0; j < PT; ++j) {
         const int px = (wp * PT + j) * 16 + fr;
         int hb = 0, kb = 0;
-        if (px < p.TH * p.W) {
-            const int oy = px / p.W, ox = px - oy * p.W;
-            hb = oy * HW + ox;
-            kb = hb - 2 * oy;
+        if (px < p.G * IPX) {
+            const int gi = px / IPX, r = px - gi * IPX;
+            const int oy = r / p.W, ox = r - oy * p.W;
+            hb = gi * IH + oy * HW + ox;
+            kb = hb - 2 * (gi * (p.TH + 2) + oy);
         }
         hoff[j] = hb * (HK * 2);
         kbs[j] = kb;
@@ -184,11 +189,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_halo_kernel(HaloP p) {
     int hoffx = 0, kbx = 0;      // SPLIT: the shared 13th pixel tile
     if constexpr (SPLIT) {
         const int px = 12 * 16 + fr;
-        if (px < p.TH * p.W) {
-            const int oy = px / p.W, ox = px - oy * p.W;
-            const int hb = oy * HW + ox;
+        if (px < p.G * IPX) {
+            const int gi = px / IPX, r = px - gi * IPX;
+            const int oy = r / p.W, ox = r - oy * p.W;
+            const int hb = gi * IH + oy * HW + ox;
             hoffx = hb * (HK * 2);
-            kbx = hb - 2 * oy;
+            kbx = hb - 2 * (gi * (p.TH + 2) + oy);
         }
     }
 
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_halo_kernel(HaloP p) {
     constexpr int OP = BN + 8;                         // row pitch in halves
     constexpr int CPR = BN / 8;                        // 16-B chunks per row
     half_t* ot = lds;
-    const int npx = p.TH * p.W;
+    const int npx = min(p.G, p.B - n) * IPX;           // a tile's images are consecutive: one contiguous span of pixels
     const int m_base = n * p.H * p.W + y0 * p.W;
     __syncthreads();                                   // every wave is done with the operand buffers
     if (p.res) {
@@ -493,7 +499,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_halo_kernel(HaloP p) {
     auto bias_sel = [&](int px) {
         int bsel = 0;
         if (p.bias_mode == 1) {
-            const int oy = px / p.W, ox = px - oy * p.W, ho = y0 + oy;
+            const int r = px % IPX;
+            const int oy = r / p.W, ox = r - oy * p.W, ho = y0 + oy;
             const int rc = ho == 0 ? 0 : (ho == p.H - 1 ? 2 : 1);
             const int cc = ox == 0 ? 0 : (ox == p.W - 1 ? 2 : 1);
             bsel = (rc * 3 + cc) * p.Cout;
@@ -569,7 +576,7 @@ static int launch_halo(const HaloP& p, hipStream_t s) {
     constexpr size_t opnd = (size_t)(NXBUF * XROWS * HK + 2 * BN * HK) * sizeof(half_t);
     constexpr size_t epi = (size_t)NPT * 16 * (BN + 8) * sizeof(half_t);          // output staging tile
     constexpr size_t lds = opnd > epi ? opnd : epi;
-    const int blocks = p.B * p.tiles_per_img * (p.Cout / BN);
+    const int blocks = ((p.B + p.G - 1) / p.G) * p.tiles_per_img * (p.Cout / BN);
     if constexpr (FR_DEBUG) {                  // stamped twin: debug build only
         if (p.stamps) {
             static FrDevLatch dl;
@@ -594,8 +601,9 @@ int fr_conv_halo_try(const fr_conv_args* a, hipStream_t s) {
     if (!(a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->H == a->W && a->out_f32_partial == nullptr))
         return 0;
     if (a->Cin % 64 != 0 || a->Cout % 64 != 0) return 0;
-    int TH;
-    if (a->H == 14 && a->Cout % 128 == 0) TH = 14;
+    int TH, G = 1;
+    if (a->H == 7 && a->Cout % 128 == 0) { TH = 7; G = 4; }          // four whole 7x7 images = 196 pixels per tile
+    else if (a->H == 14 && a->Cout % 128 == 0) TH = 14;
     else if (a->H == 28 && a->Cout % 128 == 0) TH = 7;
     else if (a->H == 56 && a->Cin == 64) TH = 4;                         // single-chunk variants (one halo buffer)
     else if (a->H == 112 && a->Cin == 64 && a->Cout == 64) TH = 2;
@@ -606,13 +614,14 @@ int fr_conv_halo_try(const fr_conv_args* a, hipStream_t s) {
     p.bias = a->bias; p.slope = a->slope; p.res = (const half_t*)a->residual;
     p.oscale = nullptr; p.y8 = nullptr; p.y8_mul = 0.f;
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.bias_mode = a->bias_mode;
-    p.TH = TH; p.tiles_per_img = a->H / TH;
+    p.TH = TH; p.tiles_per_img = a->H / TH; p.G = G;
     p.xbytes = (unsigned)((int64_t)a->B * a->H * a->W * a->Cin * 2);
     p.wbytes = (unsigned)((int64_t)a->Cout * 9 * a->Cin * 2);
     p.stamps = (unsigned long long*)fr_dbg_ptr("FR_DBG_STAMPS");        // always NULL in the product build
     p.stagger = fr_dbg_int("FR_HALO_STAGGER", 0);
     int rc;
-    if (a->H == 56) rc = launch_halo<1, 14, 384, 1, 4>(p, s);
+    if (a->H == 7) rc = launch_halo<2, 13, 384, 1, 4, true>(p, s);        // lean schedule; halo rows: 4 x 9 x 9 = 324
+    else if (a->H == 56) rc = launch_halo<1, 14, 384, 1, 4>(p, s);
     else if (a->H == 112) rc = launch_halo<1, 14, 512, 1, 4>(p, s);
     else {
         // 28x28 and 14x14 layers run as two lean blocks per CU.  Debug build: FR_HALO_LEAN bit 0 / bit 1 = 0 selects
@@ -658,7 +667,7 @@ extern "C" int fr_conv_nhwc_f8(const fr_conv_f8_args* a, fr_stream_t stream) {
     p.bias = a->bias; p.slope = a->slope; p.res = (const half_t*)a->residual;
     p.oscale = a->oscale; p.y8 = (unsigned char*)a->y8; p.y8_mul = a->y8_mul;
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.bias_mode = a->bias_mode;
-    p.TH = a->H == 14 ? 14 : 7; p.tiles_per_img = a->H / p.TH;
+    p.TH = a->H == 14 ? 14 : 7; p.tiles_per_img = a->H / p.TH; p.G = 1;
     p.xbytes = (unsigned)((int64_t)a->B * a->H * a->W * a->Cin);
     p.wbytes = (unsigned)((int64_t)a->Cout * 9 * a->Cin);
     p.stamps = (unsigned long long*)fr_dbg_ptr("FR_DBG_STAMPS");

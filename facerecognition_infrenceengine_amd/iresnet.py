@@ -251,8 +251,8 @@ class IResNetHIP:
             # mirror of the C dispatch (fr_conv_nhwc_f16 -> fr_conv_halo_try): halo kernel for 3x3/s1 body convs
             halo = None
             if c.k == 3 and c.stride == 1 and H == W and partial is None and c.cin % 64 == 0:
-                if H in (14, 28) and c.cout % 128 == 0:          # lean variant: BN = 128, two blocks per CU
-                    halo = "conv_halo_kernel<2, 13, %d, 1, 4, false, true, 4, false, 8, 0>" % (256 if H == 14 else 320)
+                if H in (7, 14, 28) and c.cout % 128 == 0:       # lean variant: BN = 128, two blocks per CU
+                    halo = "conv_halo_kernel<2, 13, %d, 1, 4, false, true, 4, false, 8, 0>" % {7: 384, 14: 256, 28: 320}[H]
                 elif H == 56 and c.cin == 64:
                     halo = "conv_halo_kernel<1, 14, 384, 1, 4, false, false, 4, false, 8, 0>"
                 elif H == 112 and c.cin == 64 and c.cout == 64:

@@ -66,7 +66,9 @@ def _conv_case(lib, B, H, W, Cin, Cout, k, stride, pad, bias_mode, slope, residu
     (2, 28, 28, 256, 256, 3, 2, 1, 0, False, True),      # stride-2 conv2
     (2, 56, 56, 64, 128, 1, 2, 0, 0, False, False),      # 1x1/s2 shortcut
     (1, 56, 56, 64, 64, 3, 1, 1, 1, True, False),        # 64-cout tile shape
-    (5, 7, 7, 512, 512, 3, 1, 1, 0, False, True),        # 7x7 stage, ragged M = 245
+    (5, 7, 7, 512, 512, 3, 1, 1, 0, False, True),        # 7x7 stage (halo kernel, 4 images per tile), ragged: 4 + 1 images
+    (9, 7, 7, 512, 512, 3, 1, 1, 1, True, False),        # 7x7 stage conv1: border-class bias + PReLU, 4 + 4 + 1 images
+    (4, 7, 7, 256, 128, 3, 1, 1, 1, True, True),         # 7x7, one full tile, other channel counts
     (1, 9, 5, 64, 64, 3, 1, 1, 1, True, True),           # tiny odd image
     (3, 56, 56, 64, 64, 3, 1, 1, 0, False, True),        # halo kernel, single-chunk 56x56 variant + residual
     (2, 112, 112, 64, 64, 3, 1, 1, 1, True, False),      # halo kernel, 112x112 variant
