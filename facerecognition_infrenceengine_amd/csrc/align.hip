@@ -8,7 +8,8 @@
 __constant__ double ARC_DST[5][2] = {{38.2946, 51.6963}, {73.5318, 51.5014}, {56.0252, 71.7366},
                                      {41.5493, 92.3655}, {70.7299, 92.2041}};
 
-__global__ __launch_bounds__(256) void warp_affine_5pt(const uint8_t* __restrict__ frames, int H, int W,
+typedef unsigned long long u64_unaligned_w __attribute__((aligned(1)));
+__global__ __launch_bounds__(256) void warp_affine_5pt(const uint8_t* __restrict__ frames, int nframes, int H, int W,
                                                        const float* __restrict__ kps,
                                                        const int32_t* __restrict__ frame_idx,
                                                        const int32_t* __restrict__ count,
@@ -45,7 +46,9 @@ __global__ __launch_bounds__(256) void warp_affine_5pt(const uint8_t* __restrict
         inv[5] = -(inv[3] * tx + inv[4] * ty);
     }
     __syncthreads();
-    const uint8_t* fr = frames + (int64_t)(valid ? (slot_counts ? f / slot_cap : frame_idx[f]) : 0) * H * W * 3;
+    const int fidx = valid ? (slot_counts ? f / slot_cap : frame_idx[f]) : 0;
+    const uint8_t* fr = frames + (int64_t)fidx * H * W * 3;
+    const long long lim = fidx == nframes - 1 ? (long long)H * W * 3 - 8 : (1ll << 62);     // last frame: never read past the buffer
     half_t* o = out + (int64_t)f * size * size * 8;
     for (int t = threadIdx.x; t < size * size; t += 256) {
         const int y = t / size, x = t - y * size;
@@ -57,18 +60,36 @@ __global__ __launch_bounds__(256) void warp_affine_5pt(const uint8_t* __restrict
             const double fx = floor(sx), fy = floor(sy);
             const double wx = sx - fx, wy = sy - fy;
             const long long x0 = (long long)fx, y0 = (long long)fy;
+            // the two columns of a source row are 6 adjacent bytes (BGR BGR): ONE unaligned 8-byte load per row when both
+            // lie inside the frame (pulled back at the very end of the last frame's buffer), byte loads otherwise
+            double pb[2][2][3];
+            const bool pair = x0 >= 0 && x0 + 1 < W;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                double p[2][2];
+            for (int a = 0; a < 2; ++a) {
+                const long long yy = y0 + a;
+                const bool row_in = yy >= 0 && yy < H;
+                if (pair && row_in) {
+                    const long long off = (yy * W + x0) * 3;
+                    const long long c8 = off < lim ? off : lim;
+                    const unsigned long long q = *reinterpret_cast<const u64_unaligned_w*>(fr + c8) >> ((off - c8) * 8);
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+                    for (int c = 0; c < 3; ++c) {
+                        pb[a][0][c] = (double)(unsigned)((q >> (8 * c)) & 0xff);
+                        pb[a][1][c] = (double)(unsigned)((q >> (24 + 8 * c)) & 0xff);
+                    }
+                } else {
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
-                        long long yy = y0 + a, xx = x0 + b;
-                        bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
-                        p[a][b] = in ? (double)fr[((int64_t)yy * W + xx) * 3 + c] : 0.0;
+                        const long long xx = x0 + b;
+                        const bool in = row_in && xx >= 0 && xx < W;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) pb[a][b][c] = in ? (double)fr[((int64_t)yy * W + xx) * 3 + c] : 0.0;
                     }
-                double v = (1 - wy) * ((1 - wx) * p[0][0] + wx * p[0][1]) + wy * ((1 - wx) * p[1][0] + wx * p[1][1]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double v = (1 - wy) * ((1 - wx) * pb[0][0][c] + wx * pb[0][1][c]) + wy * ((1 - wx) * pb[1][0][c] + wx * pb[1][1][c]);
                 double r = floor(v + 0.5);
                 r = r < 0 ? 0 : (r > 255 ? 255 : r);
                 u[c] = (unsigned char)r;
@@ -93,7 +114,7 @@ extern "C" int fr_warp_affine_5pt(const uint8_t* frames, int nframes, int H, int
     if (F <= 0) return FR_OK;
     FR_REQUIRE(frames && kps && frame_idx && out_f16_nhwc8, "fr_warp_affine_5pt: null pointer");
     FR_REQUIRE(nframes > 0 && H > 0 && W > 0 && size > 0, "fr_warp_affine_5pt: bad size");
-    warp_affine_5pt<<<F, 256, 0, fr_stream(stream)>>>(frames, H, W, kps, frame_idx, count, nullptr, 1, size,
+    warp_affine_5pt<<<F, 256, 0, fr_stream(stream)>>>(frames, nframes, H, W, kps, frame_idx, count, nullptr, 1, size,
                                                       reinterpret_cast<half_t*>(out_f16_nhwc8), out_u8_bgr, M_out);
     FR_CHECK_LAUNCH("warp_affine_5pt");
     return FR_OK;
@@ -106,7 +127,7 @@ extern "C" int fr_warp_affine_5pt_slots(const uint8_t* frames, int nframes, int 
                                         fr_stream_t stream) {
     FR_REQUIRE(frames && kps && counts && out_f16_nhwc8 && nframes > 0 && cap > 0 && H > 0 && W > 0 && size > 0,
                "fr_warp_affine_5pt_slots: bad argument");
-    warp_affine_5pt<<<nframes * cap, 256, 0, fr_stream(stream)>>>(frames, H, W, kps, nullptr, nullptr, counts, cap, size,
+    warp_affine_5pt<<<nframes * cap, 256, 0, fr_stream(stream)>>>(frames, nframes, H, W, kps, nullptr, nullptr, counts, cap, size,
                                                                   reinterpret_cast<half_t*>(out_f16_nhwc8), nullptr, nullptr);
     FR_CHECK_LAUNCH("warp_affine_5pt");
     return FR_OK;
