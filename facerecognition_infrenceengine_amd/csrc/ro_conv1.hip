@@ -1,0 +1,321 @@
+// MTCNN R-Net / O-Net first layer, fused with the crop that feeds it: zero-padded crop of trunc(box) from the u8 BGR
+// frame -> bilinear resize to S x S (24 / 48) -> conv 3x3 (3 -> 28 / 32) -> PReLU -> 3x3 / stride 2 ceil-mode max pool
+// (11 x 11 / 23 x 23), f32 end to end (part of FaceAnalysis.get, /root/reference/infrenceServer.py:528; the arithmetic
+// of fr_crop_resize_norm and of layers 10 / 20 of fr_dconv_mfma_f32, which this replaces on the product path and
+// must equal bit for bit: tests/test_gpu_detect.py).
+//
+// Why: the stand-alone crop kernel wrote 302 + 151 MB of f32 crops per 64-frame batch only for these layers to read
+// them back, and on the 16x16x4 MFMA the layers used 27 of 36 K rows and 28 of 32 couts.  Here one block owns one crop
+// slot: the resized crop is built in LDS (lerp tables per crop; the source pixels of a row pair come from one
+// unaligned 8-byte load when both columns lie in the frame), the conv runs on v_mfma_f32_4x4x1 with a BROADCAST
+// weight operand (see pnet_conv1.hip: K = 27 exactly, a conv pixel per lane, NG cout quads), conv pixels are
+// flattened (64 per unit, a lane's 3x3 window = 27 LDS reads at constant offsets from its base), the conv map goes to
+// an LDS tile [pixel][28 | 36] and is pooled from there, in bands of 4 (R-Net) / 2 (O-Net) pooled rows so that several
+// blocks fit a CU.  A block walks 8 / 4 consecutive slots and fetches the next valid slot's source bytes (raw, into
+// registers) under the current slot's conv.  When every PReLU slope is >= 0 the raw sums are pooled first and
+// activated after (the same bits, a ninth of the bias / PReLU work); otherwise every pixel is activated before the pool.
+// Count-aware like the other R-/O-Net layers: a slot >= counts[frame] does no work and leaves its output unwritten.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+struct RoArgs {
+    const uint8_t* frames; int nframes, H, W;
+    const float* boxes; const int32_t* counts; int cap;
+    const float* w;                            // [27][NG * 4] f32: k = (kh * 3 + kw) * 3 + channel (R, G, B)
+    const float* bias; const float* slope;     // [NG * 4]
+    float* y;                                  // [slots][P][P][COUT]
+};
+
+typedef unsigned long long u64_unaligned_r __attribute__((aligned(1)));
+struct LerpR { int i0, i1; float w; };
+__device__ __forceinline__ LerpR lerp_coord_r(int d, float ratio, int n) {        // == detect_ops.hip lerp_coord
+    float f = ((float)d + 0.5f) * ratio - 0.5f;
+    float fl = floorf(f);
+    LerpR r;
+    r.w = f - fl;
+    int i = (int)fl;
+    r.i0 = min(max(i, 0), n - 1);
+    r.i1 = min(max(i + 1, 0), n - 1);
+    return r;
+}
+__device__ __forceinline__ float bilerp_r(float p00, float p01, float p10, float p11, float wx, float wy) {
+    float top = (1.0f - wx) * p00 + wx * p01;
+    float bot = (1.0f - wx) * p10 + wx * p11;
+    return (1.0f - wy) * top + wy * bot;
+}
+__device__ __forceinline__ float vmax_r(float x, float y) {        // no canonicalising self-max (operands are never sNaN)
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+
+// S: crop size; NG: cout quads (COUT = 4 NG real channels written); PB: pooled rows per band (a band = 2 PB + 1 conv rows);
+// RPB: consecutive crop slots per block.  The source bytes of the NEXT valid slot's crop are fetched (raw, into
+// registers) before the current slot's conv and blended into LDS after it, so the frame gather's latency is covered.
+template <int S, int NG, int COUT, int PB, int RPB>
+__global__ __launch_bounds__(256) void crop_conv1_kernel(RoArgs a) {
+    constexpr int C = S - 2;                                     // conv map size
+    constexpr int P = (C - 3 + 1) / 2 + 1;                       // ceil((C - 3) / 2) + 1 pooled size (ceil mode)
+    // conv tile pixel stride in floats: 16-B rows whose stride is NOT a multiple of 32 words, so that 8 consecutive lanes'
+    // 16-byte accesses fall into 8 different bank groups (28 words for R-Net's 28 channels as they are; 32 + 4 for O-Net)
+    constexpr int CS = (NG * 4) % 32 ? NG * 4 : NG * 4 + 4;
+    constexpr int BR = 2 * PB + 1 < C ? 2 * PB + 1 : C;          // conv rows per band
+    constexpr int NBAND = (P + PB - 1) / PB;
+    constexpr int NPF = (S * S + 255) / 256;                     // crop pixels per thread
+    static_assert(NG * 4 <= 32 && COUT <= NG * 4, "cout quads");
+    constexpr int NW = (27 * NG + 15) / 16;                      // weight registers
+    extern __shared__ __attribute__((aligned(16))) float lds_ro[];
+    float* xin = lds_ro;                                         // [S*S][3]
+    int4v* tab = reinterpret_cast<int4v*>(lds_ro + ((S * S * 3 + 3) & ~3));          // [2][2 S] lerp tables (double-buffered)
+    float* ot = reinterpret_cast<float*>(tab + 4 * S);           // [BR * C][CS] conv tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nslots = a.nframes * a.cap;
+    const int s_end = min((int)(blockIdx.x + 1) * RPB, nslots);
+    auto next_valid = [&](int s) {                               // first slot >= s of this block that holds a candidate, or -1
+        for (; s < s_end; ++s) {
+            const int f = s / a.cap;
+            if (s - f * a.cap < a.counts[f]) return s;
+        }
+        return -1;
+    };
+    int slot = next_valid(blockIdx.x * RPB);
+    if (slot < 0) return;                                        // only empty slots: no work, outputs unwritten
+
+    // ---- weights: slot c = k * NG + g -> lanes 4 (c % 16) + r of register c / 16 hold W[k][4g + r]
+    float wreg[NW];
+#pragma unroll
+    for (int v = 0; v < NW; ++v) {
+        const int c = v * 16 + (lane >> 2), r = lane & 3;
+        wreg[v] = c < 27 * NG ? a.w[(c / NG) * (NG * 4) + (c % NG) * 4 + r] : 0.f;
+    }
+    bool mono = true;
+    for (int c = 0; c < NG * 4; ++c) mono = mono && a.slope[c] >= 0.f;
+
+    // ---- the crop (fr_crop_resize_norm's arithmetic).  Per slot: tables of its S rows and S columns {first source
+    // index in frame coordinates, second, weight, -}; per crop pixel two 8-byte row pieces fetched RAW plus flags:
+    //   bits 0-1: what p(.,0) is (0 zero - column outside the frame, 1 first pixel of the piece), bits 2-3: what p(.,1)
+    //   is (0 zero, 1 first pixel - clamped: x1 = x0, or x0 outside, 2 second pixel), bits 8-15 / 16-23: pull-back of the
+    //   two loads in bits (last bytes of the last frame); -1: the whole pixel is zero (empty box)
+    unsigned long long rq0[NPF], rq1[NPF];
+    int rfl[NPF];
+    bool edge = true;                                            // wave-uniform: some pixel is not the plain two-column case
+    auto make_tab = [&](int sl, int buf) __attribute__((always_inline)) {
+        if (tid < 2 * S) {
+            const float4 b = *reinterpret_cast<const float4*>(a.boxes + (int64_t)sl * 4);
+            const int x1 = (int)truncf(b.x), y1 = (int)truncf(b.y), x2 = (int)truncf(b.z), y2 = (int)truncf(b.w);
+            const int tw = x2 - x1 + 1, th = y2 - y1 + 1;
+            int4v e = {0, 0, 0, 0};                              // e[3] = 1: the box is not empty
+            if (tw > 0 && th > 0) {
+                if (tid < S) {
+                    const LerpR l = lerp_coord_r(tid, (float)th / (float)S, th);
+                    e = int4v{y1 - 1 + l.i0, y1 - 1 + l.i1, __float_as_int(l.w), 1};
+                } else {
+                    const LerpR l = lerp_coord_r(tid - S, (float)tw / (float)S, tw);
+                    e = int4v{x1 - 1 + l.i0, x1 - 1 + l.i1, __float_as_int(l.w), 1};
+                }
+            }
+            tab[buf * 2 * S + tid] = e;
+        }
+    };
+    auto load_crop = [&](int sl, int buf) __attribute__((always_inline)) {
+        const int f = sl / a.cap;
+        const uint8_t* fr = a.frames + (int64_t)f * a.H * a.W * 3;
+        const int lim = f == a.nframes - 1 ? a.H * a.W * 3 - 8 : 0x7fffffff;
+        bool special = false;
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int t = min(tid + u * 256, S * S - 1);         // threads past the crop: any valid pixel, never stored
+            const int oy = t / S, ox = t - oy * S;
+            const int4v re = tab[buf * 2 * S + oy], ce = tab[buf * 2 * S + S + ox];
+            rq0[u] = rq1[u] = 0; rfl[u] = -1;
+            if (re[3]) {
+                const int xs0 = ce[0], xs1 = ce[1];
+                const bool in0 = xs0 >= 0 && xs0 < a.W, in1 = xs1 >= 0 && xs1 < a.W;
+                const int basecol = in0 ? xs0 : xs1;
+                const int src0 = in0 ? 1 : 0;
+                const int src1 = in1 ? (xs1 == basecol ? 1 : 2) : 0;
+                int fl = src0 | (src1 << 2);
+                if (src0 | src1) {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const int ys = r ? re[1] : re[0];
+                        if (ys >= 0 && ys < a.H) {
+                            const int off = (ys * a.W + basecol) * 3;
+                            const int c8 = min(off, lim);
+                            const unsigned long long q = *reinterpret_cast<const u64_unaligned_r*>(fr + c8);
+                            if (r) rq1[u] = q; else rq0[u] = q;
+                            fl |= ((off - c8) * 8) << (8 + 8 * r);
+                        }
+                    }
+                }
+                rfl[u] = fl;
+                special = special || fl != (1 | (2 << 2));
+            }
+        }
+        edge = __builtin_amdgcn_ballot_w64(special) != 0;
+    };
+    auto store_crop_as = [&](int buf, auto EDGE) __attribute__((always_inline)) {
+        constexpr bool E = decltype(EDGE)::value;
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int t = tid + u * 256;
+            if (t >= S * S) continue;
+            const int oy = t / S, ox = t - oy * S;
+            const float wy = __int_as_float(tab[buf * 2 * S + oy][2]), wx = __int_as_float(tab[buf * 2 * S + S + ox][2]);
+            float v[3] = {0.f, 0.f, 0.f};
+            if (rfl[u] >= 0) {
+                const unsigned long long q0 = E ? rq0[u] >> ((rfl[u] >> 8) & 0xff) : rq0[u];
+                const unsigned long long q1 = E ? rq1[u] >> ((rfl[u] >> 16) & 0xff) : rq1[u];
+                const unsigned l0 = (unsigned)q0, h0 = (unsigned)(q0 >> 32), l1 = (unsigned)q1, h1 = (unsigned)(q1 >> 32);
+                // bytes of a row piece: B0 G0 R0 B1 | G1 R1 . .  ; channel order R, G, B
+                const float f0[3] = {(float)((l0 >> 16) & 0xff), (float)((l0 >> 8) & 0xff), (float)(l0 & 0xff)};
+                const float s0[3] = {(float)((h0 >> 8) & 0xff), (float)(h0 & 0xff), (float)(l0 >> 24)};
+                const float f1[3] = {(float)((l1 >> 16) & 0xff), (float)((l1 >> 8) & 0xff), (float)(l1 & 0xff)};
+                const float s1[3] = {(float)((h1 >> 8) & 0xff), (float)(h1 & 0xff), (float)(l1 >> 24)};
+                const int src0 = rfl[u] & 3, src1 = (rfl[u] >> 2) & 3;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float p00 = E ? (src0 ? f0[ch] : 0.f) : f0[ch], p10 = E ? (src0 ? f1[ch] : 0.f) : f1[ch];
+                    const float p01 = E ? (src1 == 2 ? s0[ch] : (src1 == 1 ? f0[ch] : 0.f)) : s0[ch];
+                    const float p11 = E ? (src1 == 2 ? s1[ch] : (src1 == 1 ? f1[ch] : 0.f)) : s1[ch];
+                    v[ch] = (bilerp_r(p00, p01, p10, p11, wx, wy) - 127.5f) * 0.0078125f;
+                }
+            }
+            xin[t * 3 + 0] = v[0]; xin[t * 3 + 1] = v[1]; xin[t * 3 + 2] = v[2];
+        }
+    };
+
+    make_tab(slot, 0);
+    __syncthreads();
+    load_crop(slot, 0);
+    for (int buf = 0; slot >= 0; buf ^= 1) {
+    const int nslot = next_valid(slot + 1);
+    if (edge) store_crop_as(buf, std::true_type{});
+    else store_crop_as(buf, std::false_type{});
+    if (nslot >= 0) make_tab(nslot, buf ^ 1);
+    __syncthreads();                                             // the crop and the next slot's tables are in LDS
+    if (nslot >= 0) load_crop(nslot, buf ^ 1);                   // global loads fly under this slot's conv
+
+    float* yo = a.y + (int64_t)slot * P * P * COUT;
+    for (int band = 0; band < NBAND; ++band) {
+        const int r0 = band * 2 * PB;                                         // first conv row of the band
+        const int nrow = min(BR, C - r0);
+        const int npx = nrow * C;
+        // ---- conv: units of 64 flattened conv pixels, one unit per wave at a time
+        for (int u = wave; u * 64 < npx; u += 4) {
+            const int pidx = min(u * 64 + lane, npx - 1);                    // lanes past the band: any valid pixel, not stored
+            const int ly = pidx / C, lx = pidx - ly * C;
+            const float* xb = xin + ((r0 + ly) * S + lx) * 3;
+            float4v acc[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = float4v{0.f, 0.f, 0.f, 0.f};
+            // k = (kh, kw, channel) ascending, one fma per k: the chain of the 16x16x4 form
+            static_for<27>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                constexpr int kh = k / 9, q = k - kh * 9;                    // q = kw * 3 + channel
+                const float xv = xb[kh * S * 3 + q];
+                static_for<NG>([&](auto G) {
+                    constexpr int g = decltype(G)::value;
+                    constexpr int c = k * NG + g;
+                    acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[c / 16], xv, acc[g], 4, c % 16, 0);
+                });
+            });
+            if (u * 64 + lane < npx) {
+                float* o = ot + (u * 64 + lane) * CS;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    float4v v = acc[g];
+                    if (!mono) {
+                        v += *reinterpret_cast<const float4v*>(a.bias + g * 4);
+                        const float4v sv = *reinterpret_cast<const float4v*>(a.slope + g * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * sv[e];
+                    }
+                    *reinterpret_cast<float4v*>(o + g * 4) = v;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 3x3 / stride 2 ceil-mode max pool of the band's pooled rows; window positions past the map are CLAMPED onto
+        // the last valid row / column (a ceil-mode window always starts inside: the clamp repeats a value of the window)
+        const int p0 = band * PB;
+        const int prow = min(PB, P - p0);
+        constexpr int Q4 = COUT / 4;
+        for (int e = tid; e < prow * P * Q4; e += 256) {
+            const int qd = e % Q4, pp = e / Q4;
+            const int pyl = pp / P, px = pp - pyl * P;
+            float4v m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int ry = min(2 * pyl + dy, nrow - 1);                   // band-local conv row
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int cx = min(2 * px + dx, C - 1);
+                    const float4v v = *reinterpret_cast<const float4v*>(ot + (ry * C + cx) * CS + qd * 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) m[k] = vmax_r(m[k], v[k]);
+                }
+            }
+            if (mono) {
+                m += *reinterpret_cast<const float4v*>(a.bias + qd * 4);
+                const float4v sv = *reinterpret_cast<const float4v*>(a.slope + qd * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m[k] = m[k] > 0.f ? m[k] : m[k] * sv[k];
+            }
+            *reinterpret_cast<float4v*>(yo + ((int64_t)(p0 + pyl) * P + px) * COUT + qd * 4) = m;
+        }
+        if (band + 1 < NBAND) __syncthreads();                               // the next band overwrites the conv tile
+    }
+    __syncthreads();                                             // every wave is done with this slot's crop and conv tile
+    slot = nslot;
+    }
+}
+
+template <int S, int NG, int COUT, int PB, int RPB>
+int launch_ro(const RoArgs& a, int nslots, hipStream_t s) {
+    constexpr int C = S - 2;
+    constexpr int rows = 2 * PB + 1 < C ? 2 * PB + 1 : C;
+    constexpr int CS = (NG * 4) % 32 ? NG * 4 : NG * 4 + 4;
+    const size_t lds = (size_t)(((S * S * 3 + 3) & ~3) + 4 * S * 4 + rows * C * CS) * sizeof(float);
+    auto kern = crop_conv1_kernel<S, NG, COUT, PB, RPB>;
+    if (lds > 64 * 1024) {
+        static FrDevLatch latch;
+        if (!fr_raise_lds(reinterpret_cast<const void*>(kern), lds, latch)) {
+            fr_set_error("fr_crop_conv1_f32: cannot raise dynamic LDS to %zu bytes", lds);
+            return FR_E_LAUNCH;
+        }
+    }
+    kern<<<(nslots + RPB - 1) / RPB, 256, lds, s>>>(a);
+    return FR_OK;
+}
+
+}  // namespace
+
+extern "C" int fr_crop_conv1_f32(int net, const uint8_t* frames, int nframes, int H, int W, const float* boxes,
+                                 const int32_t* counts, int cap, const float* w, const float* bias, const float* slope,
+                                 float* y, fr_stream_t stream) {
+    FR_REQUIRE(frames && boxes && counts && w && bias && slope && y, "fr_crop_conv1_f32: null pointer");
+    FR_REQUIRE(nframes > 0 && cap > 0 && H > 0 && W > 0 && (int64_t)H * W * 3 < (1ll << 31) && (int64_t)H * W * 3 >= 8,
+               "fr_crop_conv1_f32: bad frame size");
+    FR_REQUIRE((int64_t)nframes * cap < (1ll << 31), "fr_crop_conv1_f32: too many slots");
+    RoArgs a{frames, nframes, H, W, boxes, counts, cap, w, bias, slope, y};
+    int rc;
+    // bands of 4 / 2 pooled rows keep the conv tile at 22 / 33 KB (5 / 2 blocks per CU); 8 / 4 slots per block (measured:
+    // one band 785 / 626 us, these bands with one slot per block 569 / 369, as below 508 / 356 us per 64-frame batch)
+    if (net == 0) rc = launch_ro<24, 7, 28, 4, 8>(a, nframes * cap, fr_stream(stream));          // R-Net: 24 -> 22 -> 11
+    else if (net == 1) rc = launch_ro<48, 8, 32, 2, 4>(a, nframes * cap, fr_stream(stream));      // O-Net: 48 -> 46 -> 23
+    else { FR_REQUIRE(false, "fr_crop_conv1_f32: net must be 0 (R-Net) or 1 (O-Net)"); }
+    if (rc != FR_OK) return rc;
+    FR_CHECK_LAUNCH("crop_conv1_kernel");
+    return FR_OK;
+}

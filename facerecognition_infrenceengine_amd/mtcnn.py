@@ -149,6 +149,12 @@ class MTCNNHIP:
             w2p, p["conv2.bias"], p["prelu2.weight"], w3p, p["conv3.bias"], p["prelu3.weight"], hw.t().contiguous(), hb))
         self.refine_margin = 2e-3           # in logit units, ~200x the split-precision error
         self.refined_cells = None           # optional device int32[1]: cells re-evaluated exactly (diagnostics)
+        # first R-/O-Net layer fused with the crop (csrc/ro_conv1.hip): weights as [k = (kh, kw, channel)][cout]
+        self.fused_crop = True
+        self._rc1 = tuple(t.to(torch.float32).contiguous().to(d) for t in (
+            r["conv1.weight"].permute(2, 3, 1, 0).reshape(27, 28), r["conv1.bias"], r["prelu1.weight"]))
+        self._oc1 = tuple(t.to(torch.float32).contiguous().to(d) for t in (
+            o["conv1.weight"].permute(2, 3, 1, 0).reshape(27, 32), o["conv1.bias"], o["prelu1.weight"]))
         self.r1 = _MConv(10, r["conv1.weight"], r["conv1.bias"], r["prelu1.weight"], d)
         self.r2 = _MConv(11, r["conv2.weight"], r["conv2.bias"], r["prelu2.weight"], d)
         self.r3 = _MConv(12, r["conv3.weight"], r["conv3.bias"], r["prelu3.weight"], d)
@@ -241,19 +247,36 @@ class MTCNNHIP:
         head, h, w = self._dconv(x, self.p3, N, h, w)
         return head, h, w
 
-    def rnet(self, x, B, counts=None, cap=0):
-        """counts / cap: only the first counts[frame] of a frame's cap crop slots are computed (device-side)."""
+    def crop_conv1(self, net, frames, boxes, counts, cap):
+        """frames u8 [N,H,W,3], boxes f32 [N,cap,4], counts i32 [N] -> the net's pooled conv1 map of every valid slot."""
+        N, H, W, _ = frames.shape
+        w, b, s = self._rc1 if net == 0 else self._oc1
+        p, c = (11, 28) if net == 0 else (23, 32)
+        y = self._f32(N * cap, p, p, c)
+        self.lib.fr_crop_conv1_f32(net, _lib.ptr(frames), N, H, W, _lib.ptr(boxes), _lib.ptr(counts), cap, _lib.ptr(w),
+                                   _lib.ptr(b), _lib.ptr(s), _lib.ptr(y), self._s)
+        return y
+
+    def rnet(self, x, B, counts=None, cap=0, x1=None):
+        """counts / cap: only the first counts[frame] of a frame's cap crop slots are computed (device-side).
+        x1: conv1's pooled map when it was computed straight from the frames (crop_conv1)."""
         k = dict(counts=counts, cap=cap)
-        x, h, w = self._dconv(x, self.r1, B, 24, 24, **k)   # + fused 3x3/s2 pool -> 11x11
+        if x1 is not None:
+            x, h, w = x1, 11, 11
+        else:
+            x, h, w = self._dconv(x, self.r1, B, 24, 24, **k)   # + fused 3x3/s2 pool -> 11x11
         x, h, w = self._dconv(x, self.r2, B, h, w, **k)     # + fused 3x3/s2 pool -> 4x4
         x, h, w = self._dconv(x, self.r3, B, h, w, **k)
         x, h, w = self._dconv(x, self.r4, B, h, w, **k)
         x, h, w = self._dconv(x, self.r5, B, 1, 1, **k)
         return x.reshape(B, 6)
 
-    def onet(self, x, B, counts=None, cap=0):
+    def onet(self, x, B, counts=None, cap=0, x1=None):
         k = dict(counts=counts, cap=cap)
-        x, h, w = self._dconv(x, self.o1, B, 48, 48, **k)   # + fused 3x3/s2 pool -> 23x23
+        if x1 is not None:
+            x, h, w = x1, 23, 23
+        else:
+            x, h, w = self._dconv(x, self.o1, B, 48, 48, **k)   # + fused 3x3/s2 pool -> 23x23
         x, h, w = self._dconv(x, self.o2, B, h, w, **k)     # + fused 3x3/s2 pool -> 10x10
         x, h, w = self._dconv(x, self.o3, B, h, w, **k)     # + fused 2x2/s2 pool -> 4x4
         x, h, w = self._dconv(x, self.o4, B, h, w, **k)
@@ -330,10 +353,14 @@ class MTCNNHIP:
                 trace.update(stage1_boxes=b1, stage1_scores=s1, stage1_counts=c1)
             # ---- stage 2
             B2 = N * self.cap_p
-            crops = self._f32(B2, 24, 24, 4)
-            lib.fr_crop_resize_norm(_lib.ptr(frames), N, H, W, _lib.ptr(b1), _lib.ptr(c1), self.cap_p, 24,
-                                    _lib.ptr(crops), self._s)
-            head2 = self.rnet(crops, B2, c1, self.cap_p)
+            crops = None
+            if self.fused_crop and trace is None:       # crop + conv1 + pool in one kernel: no crop tensor in HBM
+                head2 = self.rnet(None, B2, c1, self.cap_p, x1=self.crop_conv1(0, frames, b1, c1, self.cap_p))
+            else:
+                crops = self._f32(B2, 24, 24, 4)
+                lib.fr_crop_resize_norm(_lib.ptr(frames), N, H, W, _lib.ptr(b1), _lib.ptr(c1), self.cap_p, 24,
+                                        _lib.ptr(crops), self._s)
+                head2 = self.rnet(crops, B2, c1, self.cap_p)
             sb, ss, sa, sc = self._f32(N, self.cap_p, 4), self._f32(N, self.cap_p), self._f32(N, self.cap_p, 4), self._i32(N)
             prob2 = self._f32(N, self.cap_p) if trace is not None else None
             lib.fr_stage_select(_lib.ptr(b1), _lib.ptr(head2), 6, _lib.ptr(c1), N, self.cap_p, t1, _lib.ptr(sb),
@@ -345,10 +372,13 @@ class MTCNNHIP:
                              stage2_counts=c2)
             # ---- stage 3
             B3 = N * self.cap_r
-            crops3 = self._f32(B3, 48, 48, 4)
-            lib.fr_crop_resize_norm(_lib.ptr(frames), N, H, W, _lib.ptr(b2), _lib.ptr(c2), self.cap_r, 48,
-                                    _lib.ptr(crops3), self._s)
-            head3 = self.onet(crops3, B3, c2, self.cap_r)
+            if self.fused_crop and trace is None:
+                head3 = self.onet(None, B3, c2, self.cap_r, x1=self.crop_conv1(1, frames, b2, c2, self.cap_r))
+            else:
+                crops3 = self._f32(B3, 48, 48, 4)
+                lib.fr_crop_resize_norm(_lib.ptr(frames), N, H, W, _lib.ptr(b2), _lib.ptr(c2), self.cap_r, 48,
+                                        _lib.ptr(crops3), self._s)
+                head3 = self.onet(crops3, B3, c2, self.cap_r)
             tb, ts, ta, tc = self._f32(N, self.cap_r, 4), self._f32(N, self.cap_r), self._f32(N, self.cap_r, 14), self._i32(N)
             prob3 = self._f32(N, self.cap_r) if trace is not None else None
             lib.fr_stage_select(_lib.ptr(b2), _lib.ptr(head3), 16, _lib.ptr(c2), N, self.cap_r, t2, _lib.ptr(tb),

@@ -233,6 +233,15 @@ int fr_dconv_mfma_f32(int layer, const float* x, const float* w, const float* bi
                       float* y, int B, int H, int W, const float* head_w, const float* head_b,
                       const uint8_t* frames, int FH, int FW, const int32_t* counts, int cap, void* y_split,
                       fr_stream_t stream);
+/* R-Net / O-Net first layer fused with the crop that feeds it (net 0: 24x24 crop -> conv 3->28 -> PReLU -> 3x3/s2 ceil
+ * pool -> y f32 [nframes*cap, 11, 11, 28]; net 1: 48x48 -> conv 3->32 -> ... -> [nframes*cap, 23, 23, 32]): the
+ * arithmetic of fr_crop_resize_norm followed by layer 10 / 20 of fr_dconv_mfma_f32, bit for bit, without the crop
+ * tensor in HBM.  boxes f32 [nframes*cap, 4] (trunc'ed inside), counts i32 [nframes]: slot j of frame f is computed
+ * iff j < counts[f], other outputs stay unwritten.  w f32 [27][Cout]: k = (kh*3 + kw)*3 + channel (R, G, B);
+ * bias / slope f32 [Cout]. */
+int fr_crop_conv1_f32(int net, const uint8_t* frames, int nframes, int H, int W, const float* boxes,
+                      const int32_t* counts, int cap, const float* w, const float* bias, const float* slope,
+                      float* y, fr_stream_t stream);
 /* P-Net conv2 -> PReLU -> conv3 -> PReLU -> heads fused, on the f16 matrix cores with split-precision operands
  * (x = hi + lo in f16, three MFMAs per product term, f32 accumulate; ~1e-5 logit error), followed by an EXACT f32
  * re-evaluation of every cell whose logit1 - logit0 >= refine_logit_thr (pass ln(t/(1-t)) - 2e-3 for threshold t):

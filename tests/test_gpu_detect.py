@@ -178,8 +178,9 @@ def test_count_aware_rnet_onet_equal_full_computation(det, monkeypatch):
     x = torch.from_numpy(frs).cuda()
     b1, s1, k1, c1 = det.detect_batch(x)
     orig_r, orig_o = det.rnet, det.onet
-    monkeypatch.setattr(det, "rnet", lambda t, B, counts=None, cap=0: orig_r(t, B))
-    monkeypatch.setattr(det, "onet", lambda t, B, counts=None, cap=0: orig_o(t, B))
+    monkeypatch.setattr(det, "fused_crop", False)                     # reference: stand-alone crops, EVERY slot computed
+    monkeypatch.setattr(det, "rnet", lambda t, B, counts=None, cap=0, x1=None: orig_r(t, B))
+    monkeypatch.setattr(det, "onet", lambda t, B, counts=None, cap=0, x1=None: orig_o(t, B))
     b0, s0, k0, c0 = det.detect_batch(x)
     assert torch.equal(c0, c1) and int(c1[1]) == 0 and int(c1.sum()) >= 1
     for f in range(3):
@@ -278,3 +279,43 @@ def test_pnet_conv1_kernel_vs_oracle_and_16x16x4_form(negative_slopes):
             got = outs[0][0][0, :, :, :10].cpu().numpy()
             np.testing.assert_allclose(got, want, atol=3e-5, rtol=1e-5)
             assert float(outs[0][0][..., 10:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("negative_slopes", [False, True])
+def test_crop_conv1_equals_crop_then_layer(negative_slopes):
+    """R-/O-Net's first layer runs fused with the crop (csrc/ro_conv1.hip: crop -> resize -> conv 3x3 on 4x4x1 MFMAs ->
+    PReLU -> 3x3/s2 ceil pool, no crop tensor in HBM).  Must equal fr_crop_resize_norm followed by layer 10 / 20 of
+    fr_dconv_mfma_f32 BIT FOR BIT on every valid slot: boxes inside the frame, sticking out of every side, one pixel
+    wide, degenerate (empty), in the last frame (8-byte loads pulled back), with partially filled slot lists; also with
+    negative PReLU slopes (no pooling before the activation then)."""
+    from facerecognition_infrenceengine_amd import _lib, weights
+    from facerecognition_infrenceengine_amd.mtcnn import MTCNNHIP
+    st = weights.synth_mtcnn_states(seed=77)
+    if negative_slopes:
+        st[1]["prelu1.weight"] = st[1]["prelu1.weight"] * torch.where(torch.arange(28) % 3 == 0, -1.0, 1.0)
+        st[2]["prelu1.weight"] = st[2]["prelu1.weight"] * torch.where(torch.arange(32) % 5 == 0, -0.5, 1.0)
+    d = MTCNNHIP(*st, device="cuda:0")
+    lib = d.lib
+    N, H, W, cap = 3, 97, 131, 40
+    g = torch.Generator(device="cuda").manual_seed(11)
+    frames = torch.randint(0, 256, (N, H, W, 3), generator=g, device="cuda", dtype=torch.uint8)
+    x1 = torch.rand((N, cap), generator=g, device="cuda") * (W + 40) - 30
+    y1 = torch.rand((N, cap), generator=g, device="cuda") * (H + 40) - 30
+    sz = torch.rand((N, cap), generator=g, device="cuda") * 70 + 1
+    boxes = torch.stack([x1, y1, x1 + sz, y1 + sz * 1.2], -1).contiguous()
+    boxes[0, 0] = torch.tensor([5.0, 5.0, 5.0, 60.0])                 # one pixel wide
+    boxes[0, 1] = torch.tensor([50.0, 50.0, 40.0, 60.0])              # empty (x2 < x1)
+    boxes[2, 2] = torch.tensor([W - 3.0, H - 3.0, W + 10.0, H + 9.0])   # last frame, bottom-right corner
+    boxes[1, 3] = torch.tensor([-20.0, -20.0, W + 20.0, H + 20.0])    # larger than the frame
+    counts = torch.tensor([cap, 17, 25], dtype=torch.int32, device="cuda")
+    valid = (torch.arange(cap, device="cuda")[None, :] < counts[:, None]).reshape(-1)
+    d._s = _lib.stream_ptr()
+    for net, size, layer, c in ((0, 24, d.r1, 28), (1, 48, d.o1, 32)):
+        crops = torch.empty((N * cap, size, size, 4), dtype=torch.float32, device="cuda")
+        lib.fr_crop_resize_norm(_lib.ptr(frames), N, H, W, _lib.ptr(boxes), _lib.ptr(counts), cap, size, _lib.ptr(crops),
+                                _lib.stream_ptr())
+        want, ho, wo = d._dconv(crops, layer, N * cap, size, size, counts=counts, cap=cap)
+        got = d.crop_conv1(net, frames, boxes, counts, cap)
+        torch.cuda.synchronize()
+        assert got.shape == want.shape == (N * cap, ho, wo, c)
+        assert torch.equal(got[valid].view(torch.int32), want[valid].view(torch.int32)), net

@@ -13,6 +13,8 @@ from facerecognition_infrenceengine_amd import FaceAnalysis
 warnings.simplefilter("ignore")
 app = FaceAnalysis(name="synthetic", arch="r100", cap_o=4).prepare(ctx_id=0)
 app.det.p1.layer = int(sys.argv[1])
+if len(sys.argv) > 2:
+    app.det.fused_crop = sys.argv[2] == "1"
 frames = bench.synth_frames(64, 1080, 1920, 0, torch.device("cuda:0"))
 for _ in range(3):
     app.det.detect_batch(frames)
@@ -22,4 +24,4 @@ e0.record()
 for _ in range(10):
     app.det.detect_batch(frames)
 e1.record(); torch.cuda.synchronize()
-print("one_stream", os.environ.get("FR_DET_ONE_STREAM"), "p1 layer", sys.argv[1], "detect ms", round(e0.elapsed_time(e1) / 10, 3))
+print("one_stream", os.environ.get("FR_DET_ONE_STREAM"), "p1 layer", sys.argv[1], "fused crop", app.det.fused_crop, "detect ms", round(e0.elapsed_time(e1) / 10, 3))
