@@ -77,20 +77,20 @@ __global__ __launch_bounds__(256) void crop_conv1_kernel(RoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_ro[];
     float* xin = lds_ro;                                         // [S*S][3]
     int4v* tab = reinterpret_cast<int4v*>(lds_ro + ((S * S * 3 + 3) & ~3));          // [2][2 S] lerp tables (double-buffered)
-    float* ot = reinterpret_cast<float*>(tab + 4 * S);           // [BR * C][CS] conv tile
+    float4* sbox_mem = reinterpret_cast<float4*>(tab + 4 * S);  // [RPB] the block's boxes (one global read, off the per-slot path)
+    float* ot = reinterpret_cast<float*>(sbox_mem + RPB);        // [BR * C][CS] conv tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nslots = a.nframes * a.cap;
-    const int s_end = min((int)(blockIdx.x + 1) * RPB, nslots);
-    auto next_valid = [&](int s) {                               // first slot >= s of this block that holds a candidate, or -1
-        for (; s < s_end; ++s) {
-            const int f = s / a.cap;
-            if (s - f * a.cap < a.counts[f]) return s;
-        }
-        return -1;
-    };
-    int slot = next_valid(blockIdx.x * RPB);
-    if (slot < 0) return;                                        // only empty slots: no work, outputs unwritten
-
+    // a block's RPB consecutive slots lie in ONE frame (the host picks RPB | cap), and a frame's candidates are a prefix of
+    // its slots: the block's valid slots are the interval [slot, s_end) - one read of the count, no search
+    const int s_first = blockIdx.x * RPB;
+    const int fblk = s_first / a.cap;
+    const int s_end = min(s_first + RPB, fblk * a.cap + a.counts[fblk]);
+    int slot = s_first;
+    if (slot >= s_end) return;                                   // only empty slots: no work, outputs unwritten
+    auto next_valid = [&](int s) { return s < s_end ? s : -1; };
+    float4* sbox = sbox_mem;
+    if (tid < s_end - s_first) sbox[tid] = *reinterpret_cast<const float4*>(a.boxes + (int64_t)(s_first + tid) * 4);
+    __syncthreads();
     // ---- weights: slot c = k * NG + g -> lanes 4 (c % 16) + r of register c / 16 hold W[k][4g + r]
     float wreg[NW];
 #pragma unroll
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void crop_conv1_kernel(RoArgs a) {
     bool edge = true;                                            // wave-uniform: some pixel is not the plain two-column case
     auto make_tab = [&](int sl, int buf) __attribute__((always_inline)) {
         if (tid < 2 * S) {
-            const float4 b = *reinterpret_cast<const float4*>(a.boxes + (int64_t)sl * 4);
+            const float4 b = sbox[sl - s_first];
             const int x1 = (int)truncf(b.x), y1 = (int)truncf(b.y), x2 = (int)truncf(b.z), y2 = (int)truncf(b.w);
             const int tw = x2 - x1 + 1, th = y2 - y1 + 1;
             int4v e = {0, 0, 0, 0};                              // e[3] = 1: the box is not empty
@@ -286,7 +286,7 @@ int launch_ro(const RoArgs& a, int nslots, hipStream_t s) {
     constexpr int C = S - 2;
     constexpr int rows = 2 * PB + 1 < C ? 2 * PB + 1 : C;
     constexpr int CS = (NG * 4) % 32 ? NG * 4 : NG * 4 + 4;
-    const size_t lds = (size_t)(((S * S * 3 + 3) & ~3) + 4 * S * 4 + rows * C * CS) * sizeof(float);
+    const size_t lds = (size_t)(((S * S * 3 + 3) & ~3) + 4 * S * 4 + RPB * 4 + rows * C * CS) * sizeof(float);
     auto kern = crop_conv1_kernel<S, NG, COUT, PB, RPB>;
     if (lds > 64 * 1024) {
         static FrDevLatch latch;
@@ -312,8 +312,9 @@ extern "C" int fr_crop_conv1_f32(int net, const uint8_t* frames, int nframes, in
     int rc;
     // bands of 4 / 2 pooled rows keep the conv tile at 22 / 33 KB (5 / 2 blocks per CU); 8 / 4 slots per block (measured:
     // one band 785 / 626 us, these bands with one slot per block 569 / 369, as below 508 / 356 us per 64-frame batch)
-    if (net == 0) rc = launch_ro<24, 7, 28, 4, 8>(a, nframes * cap, fr_stream(stream));          // R-Net: 24 -> 22 -> 11
-    else if (net == 1) rc = launch_ro<48, 8, 32, 2, 4>(a, nframes * cap, fr_stream(stream));      // O-Net: 48 -> 46 -> 23
+    hipStream_t s = fr_stream(stream);
+    if (net == 0) rc = cap % 8 == 0 ? launch_ro<24, 7, 28, 4, 8>(a, nframes * cap, s) : launch_ro<24, 7, 28, 4, 1>(a, nframes * cap, s);      // R-Net: 24 -> 22 -> 11
+    else if (net == 1) rc = cap % 4 == 0 ? launch_ro<48, 8, 32, 2, 4>(a, nframes * cap, s) : launch_ro<48, 8, 32, 2, 1>(a, nframes * cap, s);  // O-Net: 48 -> 46 -> 23
     else { FR_REQUIRE(false, "fr_crop_conv1_f32: net must be 0 (R-Net) or 1 (O-Net)"); }
     if (rc != FR_OK) return rc;
     FR_CHECK_LAUNCH("crop_conv1_kernel");
