@@ -313,8 +313,10 @@ extern "C" int fr_crop_conv1_f32(int net, const uint8_t* frames, int nframes, in
     // bands of 4 / 2 pooled rows keep the conv tile at 22 / 33 KB (5 / 2 blocks per CU); 8 / 4 slots per block (measured:
     // one band 785 / 626 us, these bands with one slot per block 569 / 369, as below 508 / 356 us per 64-frame batch)
     hipStream_t s = fr_stream(stream);
-    if (net == 0) rc = cap % 8 == 0 ? launch_ro<24, 7, 28, 4, 8>(a, nframes * cap, s) : launch_ro<24, 7, 28, 4, 1>(a, nframes * cap, s);      // R-Net: 24 -> 22 -> 11
-    else if (net == 1) rc = cap % 4 == 0 ? launch_ro<48, 8, 32, 2, 4>(a, nframes * cap, s) : launch_ro<48, 8, 32, 2, 1>(a, nframes * cap, s);  // O-Net: 48 -> 46 -> 23
+    // several slots per block only when there are blocks to spare (a single frame's 512 / 64 slots want one block each)
+    const int64_t nslots = (int64_t)nframes * cap;
+    if (net == 0) rc = cap % 8 == 0 && nslots >= 8192 ? launch_ro<24, 7, 28, 4, 8>(a, nframes * cap, s) : launch_ro<24, 7, 28, 4, 1>(a, nframes * cap, s);      // R-Net: 24 -> 22 -> 11
+    else if (net == 1) rc = cap % 4 == 0 && nslots >= 2048 ? launch_ro<48, 8, 32, 2, 4>(a, nframes * cap, s) : launch_ro<48, 8, 32, 2, 1>(a, nframes * cap, s);  // O-Net: 48 -> 46 -> 23
     else { FR_REQUIRE(false, "fr_crop_conv1_f32: net must be 0 (R-Net) or 1 (O-Net)"); }
     if (rc != FR_OK) return rc;
     FR_CHECK_LAUNCH("crop_conv1_kernel");
