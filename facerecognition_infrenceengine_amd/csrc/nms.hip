@@ -8,9 +8,7 @@
 // the per-pyramid-level lists of one frame without a compaction pass).
 #include "common.h"
 
-#define NMS_T 512
-
-template <int NMAX>
+template <int NMAX, int NMS_T>
 __global__ __launch_bounds__(NMS_T) void sort_nms(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                   const float* __restrict__ aux, int naux,
                                                   const int32_t* __restrict__ counts, int nseg, int seg_cap,
@@ -117,13 +115,13 @@ extern "C" int fr_sort_nms(const float* boxes, const float* scores, const float*
     FR_REQUIRE(ntot <= 4096, "fr_sort_nms: list capacity %d exceeds 4096", ntot);
     hipStream_t s = fr_stream(stream);
     if (ntot <= 512)
-        sort_nms<512><<<L, NMS_T, 0, s>>>(boxes, scores, aux, naux, counts, nseg, seg_cap, seg_major, thr, mode, max_keep,
+        sort_nms<512, 512><<<L, 512, 0, s>>>(boxes, scores, aux, naux, counts, nseg, seg_cap, seg_major, thr, mode, max_keep,
                                           boxes_out, scores_out, aux_out, counts_out, cap_out);
     else if (ntot <= 2048)
-        sort_nms<2048><<<L, NMS_T, 0, s>>>(boxes, scores, aux, naux, counts, nseg, seg_cap, seg_major, thr, mode, max_keep,
+        sort_nms<2048, 1024><<<L, 1024, 0, s>>>(boxes, scores, aux, naux, counts, nseg, seg_cap, seg_major, thr, mode, max_keep,
                                            boxes_out, scores_out, aux_out, counts_out, cap_out);
     else
-        sort_nms<4096><<<L, NMS_T, 0, s>>>(boxes, scores, aux, naux, counts, nseg, seg_cap, seg_major, thr, mode, max_keep,
+        sort_nms<4096, 1024><<<L, 1024, 0, s>>>(boxes, scores, aux, naux, counts, nseg, seg_cap, seg_major, thr, mode, max_keep,
                                            boxes_out, scores_out, aux_out, counts_out, cap_out);
     FR_CHECK_LAUNCH("sort_nms");
     return FR_OK;
