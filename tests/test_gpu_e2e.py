@@ -260,6 +260,28 @@ def test_slot_path_with_compact_embed(app):
         assert float((1 - cos).max()) < 1e-5
 
 
+def test_frame_ingest_decodes_into_the_pinned_ring():
+    """FrameIngest.decode_into: encoded bytes (the enrolment path's GridFS blobs, trainingServer.py:219-221) land in the
+    slot's pinned buffer and reach the device unchanged; undecodable bytes and a wrong picture size are refused."""
+    import io
+    from PIL import Image
+    from facerecognition_infrenceengine_amd.ingest import FrameIngest
+    rng = np.random.default_rng(4)
+    imgs = [rng.integers(0, 256, (60, 80, 3), dtype=np.uint8) for _ in range(2)]
+    ing = FrameIngest(2, 60, 80, "cuda:0", depth=2)
+    for i, im in enumerate(imgs):
+        buf = io.BytesIO()
+        Image.fromarray(im[:, :, ::-1]).save(buf, format="PNG")           # PNG holds RGB; frames are BGR
+        assert ing.decode_into(0, i, buf.getvalue())
+    assert not ing.decode_into(0, 0, b"garbage")
+    small = io.BytesIO()
+    Image.fromarray(imgs[0][:30, :40, ::-1].copy()).save(small, format="PNG")
+    assert not ing.decode_into(0, 0, small.getvalue())
+    dev, ready = ing.upload(0)
+    ready.synchronize()
+    assert np.array_equal(dev.cpu().numpy(), np.stack(imgs))
+
+
 def test_graph_replay_equals_eager(app):
     """enable_graphs(): the captured slot pipeline gives the same Face lists as the eager path, call after call.
     The embed network sums its small-batch split-K slices in a batch-size MODE (<= 8 faces, <= 48, more: iresnet.py):
