@@ -23,5 +23,5 @@ for i, ((v, f), us) in enumerate(zip(meta, acc)):
     g = groups.setdefault(key, [0, 0.0]); g[0] += 1; g[1] += us
 print(f"{'kernel':46s} {'GF':>7s} {'n':>3s} {'us/launch':>9s} {'TF':>6s} {'ms tot':>7s}")
 for (v, gf), (n, us) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
-    print(f"{v:46s} {gf:7.1f} {n:3d} {us / n:9.1f} {gf / (us / n) * 1e3 / 1e3:6.0f} {us / 1e3:7.3f}")
+    print(f"{v:46s} {gf:7.1f} {n:3d} {us / n:9.1f} {gf / (us / n) * 1e3:6.0f} {us / 1e3:7.3f}")
 print("total ms", sum(acc) / 1e3)
