@@ -1,6 +1,9 @@
 """Dev tool: per-launch time of every conv of one r100 forward (HIP events on the launch stream)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from facerecognition_infrenceengine_amd import _lib
+if os.environ.get("FR_DEBUG_LIB"):      # A/B of debug-build switches (FR_HALO_RESPF, ...) in the real net
+    _lib.use_library(os.path.join(os.path.dirname(_lib.LIB_PATH), "libfrhip_debug.so"))
 import torch
 from facerecognition_infrenceengine_amd import weights
 from facerecognition_infrenceengine_amd.iresnet import IResNetHIP
