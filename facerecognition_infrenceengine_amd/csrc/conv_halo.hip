@@ -621,6 +621,20 @@ int fr_conv_halo_try(const fr_conv_args* a, hipStream_t s) {
     p.stagger = fr_dbg_int("FR_HALO_STAGGER", 0);
     int rc;
     if (a->H == 7) rc = launch_halo<2, 13, 384, 1, 4, true>(p, s);        // lean schedule; halo rows: 4 x 9 x 9 = 324
+    else if (FR_DEBUG && (a->H == 56 || a->H == 112) && fr_dbg_int("FR_HALO_LEAN64", 0)) {
+        if constexpr (FR_DEBUG) {
+            if (a->H == 112) rc = launch_halo<1, 14, 512, 1, 4, true>(p, s);
+            else switch (fr_dbg_int("FR_HALO_LEAN64", 0)) {     // 56x56: the lean schedule and its compile-time ablations
+                case 2: rc = launch_halo<1, 14, 384, 1, 4, true, 4, false, 8, 4>(p, s); break;    // no W DMA after the first
+                case 3: rc = launch_halo<1, 14, 384, 1, 4, true, 4, false, 8, 1>(p, s); break;    // no MFMA
+                case 4: rc = launch_halo<1, 14, 384, 1, 4, true, 4, false, 8, 2>(p, s); break;    // no fragment reads
+                case 5: rc = launch_halo<1, 14, 384, 1, 4, true, 4, false, 8, 7>(p, s); break;    // skeleton
+                case 6: rc = launch_halo<1, 14, 384, 1, 4, true, 4, false, 8, 8>(p, s); break;    // no barrier
+                default: rc = launch_halo<1, 14, 384, 1, 4, true>(p, s);
+            }
+        }
+        else rc = FR_E_INVALID;
+    }
     else if (a->H == 56) rc = launch_halo<1, 14, 384, 1, 4>(p, s);
     else if (a->H == 112) rc = launch_halo<1, 14, 512, 1, 4>(p, s);
     else {
