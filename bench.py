@@ -22,9 +22,10 @@ sys.path.insert(0, ROOT)
 # The step runs on 2 x (detector, embedder, pyramid side) streams + a copy stream.  The HIP runtime maps streams onto
 # 4 hardware queues by default; streams that share a queue serialise (measured: 2 pipes on 4 queues = 20.2 ms/step,
 # on 8 queues = 17.5 ms; with RCCL's own streams beside them 8 queues alias again: 19.0 ms, 12 or 16 queues: 17.9 ms).
-# Final build of round 2, one box, N=1: 8 queues 13.32 ms/step, 12: 13.21, 16: 13.21, 24: 13.07 (inside run-to-run noise).
+# Final build of round 2, one box, N=1: 8 queues 13.32 ms/step, 12: 13.21, 16: 13.21, 24: 13.07; three alternating repeats on
+# another box: 16 queues 13.16 / 13.01 / 13.19, 24 queues 13.04 / 13.00 / 12.87, 32 queues 12.99 -> 24.
 # Must be set before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
