@@ -9,7 +9,9 @@ embedding rows are all-gathered over RCCL before the shared match (SURVEY.md 8(e
 
 Prints ONE JSON line (rank 0).  `roofline` is the dominant kernel (the IResNet body conv on
 MFMA), timed with HIP events on its launch stream in an instrumented pass after the timed region;
-`cpu_baseline` is the CPU oracle (a port, not the reference) timed on a bounded sample.
+`cpu_baseline` is the CPU oracle (a port, not the reference) timed on a bounded sample - the first frames of the GPU's
+own batch 0 - at 1, 16 and all host threads (the best is reported); the same run is the `oracle_check` of the GPU's
+boxes / embeddings / ids for those frames, and a mismatch makes the run exit non-zero.
 """
 import argparse
 import json
@@ -51,42 +53,71 @@ def synth_frames(n, h, w, seed, device):
     return (img.permute(0, 2, 3, 1).clamp(0, 1) * 255).round().to(torch.uint8).contiguous()
 
 
-def cpu_baseline(n_frames, rows, threads=None):
-    """CPU oracle on a bounded sample of the same workload (rank 0, N == 1 only).  ``threads``: torch intra-op
-    threads for the run (None = the process default = all host cores)."""
+def cpu_baseline(frames, gallery, threads=None):
+    """CPU oracle on a bounded sample of the same workload (rank 0, N == 1 only): ``frames`` (list of uint8 HWC BGR
+    arrays - copies of the first frames of the GPU's batch 0) through oracle detect -> align -> r100 fp32 -> the
+    literal per-row Python match loop over ``gallery`` (ordered dict str(row) -> f32[512]: the rows the GPU scans, keyed
+    by strings as the reference's person ids are).  ``threads``: torch intra-op threads (None = the process default =
+    all host cores).  Returns (record, per-frame results)."""
     from facerecognition_infrenceengine_amd import weights
     from oracle import align as oalign, detect as odetect, match as omatch, nets as onets
-    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-    from make_golden import synth_frame
     default_threads = torch.get_num_threads()
     if threads:
         torch.set_num_threads(threads)
     cores = torch.get_num_threads()
     p, r, o = weights.synth_mtcnn_states()
     st = weights.synth_iresnet_state("r100")
-    rng = np.random.default_rng(1)
-    G = rng.standard_normal((rows, 512)).astype(np.float32)
-    G /= np.linalg.norm(G, axis=1, keepdims=True)
-    gal = {i: G[i] for i in range(rows)}
-    frames = [synth_frame(H, W, 100 + i) for i in range(n_frames)]
     t0 = time.perf_counter()
-    faces = 0
+    faces, results = 0, []
     for fr in frames:
         b, s, k = odetect.detect(fr, p, r, o, cap_o=FACES_PER_FRAME)
-        if len(s) == 0:
-            continue
-        crops = [oalign.norm_crop(fr, kk)[0] for kk in k]
-        x = torch.from_numpy(np.stack([oalign.crop_to_net(c) for c in crops]))
-        emb = onets.iresnet_forward(st, x, weights.IRESNET_LAYERS["r100"]).numpy()
-        for e in emb:
-            q = omatch.renormalise(e / np.linalg.norm(e))
-            omatch.decide_live(*omatch.linear_scan(q, gal))          # literal per-row Python loop
-            faces += 1
+        rec = {"bbox": b, "score": s, "kps": k, "emb": np.zeros((0, 512), np.float32), "ids": [], "dec": []}
+        if len(s):
+            crops = [oalign.norm_crop(fr, kk)[0] for kk in k]
+            x = torch.from_numpy(np.stack([oalign.crop_to_net(c) for c in crops]))
+            rec["emb"] = onets.iresnet_forward(st, x, weights.IRESNET_LAYERS["r100"]).numpy()
+            for e in rec["emb"]:
+                q = omatch.renormalise(e / np.linalg.norm(e))
+                bid, bs = omatch.linear_scan(q, gallery)                 # literal per-row Python loop
+                rec["ids"].append(-1 if bid is None else int(bid))
+                rec["dec"].append(omatch.decide_live(bid, bs)[0] is not None)
+                faces += 1
+        results.append(rec)
     dt = time.perf_counter() - t0
     torch.set_num_threads(default_threads)
-    return {"value": faces / dt, "unit": "faces/s", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "port",
-            "sample": f"{n_frames} synthetic {H}x{W} frames, {faces} faces, r100 fp32 torch-CPU + literal "
-                      f"{rows}-row Python match loop, {dt:.1f} s"}
+    return {"value": round(faces / dt, 3), "unit": "faces/s", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "port",
+            "sample": f"{len(frames)} synthetic {H}x{W} frames (the first frames of the GPU's batch 0), {faces} faces, r100 "
+                      f"fp32 torch-CPU + literal {len(gallery)}-row Python match loop, {dt:.1f} s"}, results
+
+
+def oracle_check(results, gpu, cos_tol):
+    """The CPU oracle's per-frame results against what the GPU produced for the same frames of batch 0
+    (/root/reference/infrenceServer.py:528-552: faces, embeddings, best id, decision)."""
+    out = {"frames": len(results), "faces": 0, "counts_equal": True, "boxes_max_err": 0.0, "kps_max_err": 0.0,
+           "score_max_err": 0.0, "min_cos": 1.0, "ids_equal": True, "decisions_equal": True}
+    cap = gpu["bbox"].shape[1]
+    for f, rec in enumerate(results):
+        n = len(rec["score"])
+        if n != int(gpu["counts"][f]):
+            out["counts_equal"] = False
+            continue
+        out["faces"] += n
+        for j in range(n):
+            out["boxes_max_err"] = max(out["boxes_max_err"], float(np.abs(rec["bbox"][j] - gpu["bbox"][f, j]).max()))
+            out["kps_max_err"] = max(out["kps_max_err"], float(np.abs(rec["kps"][j] - gpu["kps"][f, j]).max()))
+            out["score_max_err"] = max(out["score_max_err"], float(abs(rec["score"][j] - gpu["det_score"][f, j])))
+            a, b = rec["emb"][j].astype(np.float64), gpu["embedding"][f * cap + j].astype(np.float64)
+            out["min_cos"] = min(out["min_cos"], float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))))
+            out["ids_equal"] &= rec["ids"][j] == int(gpu["idx"][f * cap + j])
+            out["decisions_equal"] &= bool(rec["dec"][j]) == (int(gpu["dec"][f * cap + j]) == 1)
+    out["ok"] = bool(out["counts_equal"] and out["ids_equal"] and out["decisions_equal"] and out["faces"] > 0
+                     and out["boxes_max_err"] <= 5e-3 and out["kps_max_err"] <= 5e-3 and out["score_max_err"] <= 5e-5
+                     and out["min_cos"] >= 1.0 - cos_tol)
+    out["tolerances"] = {"boxes_px": 5e-3, "kps_px": 5e-3, "det_score": 5e-5, "one_minus_cos": cos_tol, "ids": "exact"}
+    for k in ("boxes_max_err", "kps_max_err", "score_max_err"):
+        out[k] = float(f"{out[k]:.3g}")
+    out["min_cos"] = round(out["min_cos"], 7)
+    return out
 
 
 def c1_latency(app, device, n=30):
@@ -149,8 +180,9 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=4)
-    ap.add_argument("--cpu-frames-1t", type=int, default=1, help="frames of the 1-thread CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU oracle leg (timed at each thread count)")
+    ap.add_argument("--cpu-threads", default="1,16,0", help="torch thread counts of the CPU leg (0 = all host cores); the "
+                                                             "best is reported as cpu_baseline, all of them in cpu_baseline_sweep")
     ap.add_argument("--no-side", action="store_true", help="skip the side measurements (value_pcie, latency_c1_ms)")
     ap.add_argument("--depth", type=int, default=3, help="steps in flight before the oldest one's ids are fetched")
     ap.add_argument("--ingest", default="resident", choices=["resident", "pinned"],
@@ -167,11 +199,15 @@ def main():
     ap.add_argument("--one-stream", action="store_true", help="detector and embedder on one stream (no overlap)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C5"],
-                    help="BASELINE.json config: C2 (default, the headline: 64x1080p, 4 faces/frame, 10k rows); C1 (1 x "
+    ap.add_argument("--workload", default=None, choices=["C1", "C2", "C3", "C4", "C5"],
+                    help="BASELINE.json config.  Default: C2 on one GPU (the headline: 64x1080p, 4 faces/frame, 10k rows) "
+                         "and C4 on several (the same frames per GPU, ONE shared 1 000 000-row gallery row-sharded over "
+                         "the ranks, f16 one-pass scan + exact re-rank, embedding rows all-gathered over RCCL); C1 (1 x "
                          "640x480, 1 face, 100 rows), C3 (8 x 4K, 16 faces/frame) and C5 (fp8 embed convs + fp8 scan of "
                          "a 10 M-row gallery row-sharded 8 ways: 1.25 M rows per GPU) are side measurements for DESIGN.md")
     args = ap.parse_args()
+    if args.workload is None:
+        args.workload = "C4" if int(os.environ.get("WORLD_SIZE", str(max(args.gpus, 1)))) > 1 else "C2"
     global FRAMES, H, W, FACES_PER_FRAME, GALLERY_ROWS
     if args.workload == "C1":
         FRAMES, H, W, FACES_PER_FRAME, GALLERY_ROWS = 1, 480, 640, 1, 100
@@ -181,6 +217,10 @@ def main():
     if args.workload == "C5":           # 10 M rows over 8 GPUs; fewer ranks keep the per-GPU shard (1.25 M rows)
         GALLERY_ROWS = 1_250_000 * world_env
         args.gallery = "f8"
+    if args.workload == "C4":           # BASELINE config 4: ONE shared 1 M-row gallery, whatever the number of ranks
+        GALLERY_ROWS = 1_000_000
+        if args.gallery == "f32":
+            args.gallery = "f16"
     if args.gallery_rows:
         GALLERY_ROWS = args.gallery_rows
 
@@ -215,25 +255,39 @@ def main():
         app = FaceAnalysis(name="synthetic", arch="r100", cap_o=FACES_PER_FRAME)
         app.prepare(ctx_id=local_rank)
 
-    # gallery: seeded unit rows, row-sharded over the ranks
-    lo, hi = shard_rows(GALLERY_ROWS, world, rank)
-    if GALLERY_ROWS > 2_000_000:            # large galleries: every rank draws only its own shard (seed = shard start)
-        g = torch.Generator(device=device).manual_seed(1 + lo)
-        Gs = torch.randn((hi - lo, 512), generator=g, device=device)
-    else:
-        g = torch.Generator(device=device).manual_seed(1)
-        Gs = torch.randn((GALLERY_ROWS, 512), generator=g, device=device)[lo:hi].contiguous()
-    gm = GalleryMatcher(device, scan=args.gallery)
-    gm.set_rows(range(lo, hi), Gs, normalise=True)
-    del Gs
-    q_max = FRAMES * FACES_PER_FRAME
-    sharded = ShardedGalleryMatcher(HipOps(gm, lo), q_max, force_exchange=args.force_exchange)
-
     nbatch = min(max(args.steps, 1), 3)
     batches = [synth_frames(FRAMES, H, W, rank * 1000 + i, device) for i in range(nbatch)]
     if args.workload == "C5":               # fp8 body convs, calibrated on the faces of the first batch
         n8 = app.calibrate_fp8(batches[0][:16])
         assert n8 > 0
+
+    # gallery: seeded unit rows, row-sharded over the ranks; every rank draws ONLY its own shard (seed = shard start)
+    lo, hi = shard_rows(GALLERY_ROWS, world, rank)
+    g = torch.Generator(device=device).manual_seed(1 + lo)
+    Gs = torch.randn((hi - lo, 512), generator=g, device=device)
+    # planted matches: every face of this rank's batches owns one row of this rank's shard =
+    # its embedding + N(0, 0.02) noise (renormalised by set_rows): top-1 is well separated (score ~ 0.9 >> 0.4), so the
+    # timed ids are meaningful, not near-tie argmaxes of random rows
+    q_max = FRAMES * FACES_PER_FRAME
+    gp = torch.Generator().manual_seed(77 + rank)
+    n_plant = min(nbatch * q_max, hi - lo)
+    plant_rows = torch.randperm(hi - lo, generator=gp)[:n_plant].to(device)          # distinct local rows
+    planted = []                            # per batch: global row per slot (-1: empty slot / no room)
+    for b in range(nbatch):
+        r0 = app.detect_embed_slots(batches[b])
+        valid = (torch.arange(FACES_PER_FRAME, device=device)[None, :] < r0["counts"][:, None]).reshape(-1)
+        rows_b = torch.full((q_max,), -1, dtype=torch.int64, device=device)
+        take = plant_rows[b * q_max:(b + 1) * q_max]
+        sel = valid.nonzero().squeeze(1)[:take.numel()]
+        rows_b[sel] = take[:sel.numel()]
+        e = r0["normed_embedding"][sel]
+        noise = torch.randn(e.shape, generator=g, device=device) * 0.02
+        Gs[rows_b[sel]] = e + noise
+        planted.append(torch.where(rows_b >= 0, rows_b + lo, rows_b).cpu())
+    gm = GalleryMatcher(device, scan=args.gallery)
+    gm.set_rows(range(lo, hi), Gs, normalise=True)
+    del Gs
+    sharded = ShardedGalleryMatcher(HipOps(gm, lo), q_max, force_exchange=args.force_exchange)
 
     ingest = None
     if args.ingest == "pinned":
@@ -336,6 +390,7 @@ def main():
     # single-stream run of the batch that step processed (cross-stream hazards are silent: DESIGN.md 4.7)
     expect = {}
     bad_step = -1
+    plant_hit = plant_all = 0
     for k, (idx_h, dec_h, cnt_h) in enumerate(results):
         src = (k % ingest.depth) % nbatch if ingest is not None else k % nbatch      # the batch step k used
         if src not in expect:
@@ -343,7 +398,13 @@ def main():
             idx2, score2 = sharded.match(r["normed_embedding"])
             dec2 = gm.decide_device(idx2, score2, 0.4)
             expect[src] = (idx2.cpu(), dec2.cpu(), r["counts"].cpu())
+            if src == 0:                    # kept for the oracle check below (host copies of batch 0's sequential run)
+                gpu0 = {kk: r[kk].cpu().numpy() for kk in ("counts", "bbox", "kps", "det_score", "embedding")}
+                gpu0["idx"], gpu0["dec"] = idx2.cpu().numpy(), dec2.cpu().numpy()
         idx2, dec2, cnt2 = expect[src]
+        pl = planted[src]
+        plant_all += int((pl >= 0).sum())
+        plant_hit += int(((pl >= 0) & (idx_h == pl) & (dec_h == 1)).sum())
         valid = (torch.arange(FACES_PER_FRAME)[None, :] < cnt2[:, None]).reshape(-1)      # empty slots are undefined
         if not (torch.equal(cnt2, cnt_h) and torch.equal(idx2[valid], idx_h[valid]) and torch.equal(dec2[valid], dec_h[valid])):
             bad_step = k if bad_step < 0 else bad_step      # no break: sharded.match above is a collective
@@ -451,7 +512,7 @@ def main():
         side["latency_c1_ms"] = c1_latency(app, device)
 
     if rank == 0:
-        out = {"metric": "faces/sec end-to-end @1080p" if args.workload == "C2" else f"faces/sec end-to-end @{H}p", "value": round(faces / dt, 1), "unit": "faces/s",
+        out = {"metric": f"faces/sec end-to-end @{H}p", "value": round(faces / dt, 1), "unit": "faces/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "fp8" if args.workload == "C5" else "f16", "data": "synthetic",
@@ -470,12 +531,34 @@ def main():
                "p50_face_latency_ms": round(float(np.percentile(batch_ms, 50)) / max(faces / world / args.steps, 1), 4),
                "stage_ms_alone": stage_ms, **side,
                "self_check": f"all {len(results)} timed steps == sequential single-stream re-run (ids, decisions, counts)",
+               "planted_top1": {"faces": plant_all, "matched_own_row": plant_hit,
+                                "note": "timed faces whose top-1 id is the gallery row planted for them (embedding + "
+                                        "N(0, 0.02), renormalised) and is accepted at 0.4; rank 0's steps"},
                "roofline": roofline}
+        fail = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_frames, GALLERY_ROWS)
-            if args.cpu_frames_1t:              # the same port on ONE thread, beside the all-core figure
-                out["cpu_baseline_1thread"] = cpu_baseline(args.cpu_frames_1t, GALLERY_ROWS, threads=1)
+            # CPU oracle leg on copies of the first frames of batch 0, against the gallery the GPU scans; its per-frame
+            # results are ALSO the check of the GPU's results for those frames (oracle_check; a mismatch fails the run)
+            nf = max(1, min(args.cpu_frames, FRAMES))
+            frames_h = list(batches[0][:nf].cpu().numpy())
+            G_h = gm.G.cpu().numpy()
+            gallery = {str(i): G_h[i] for i in range(G_h.shape[0])}
+            sweep, res0 = [], None
+            for t in [int(v) for v in args.cpu_threads.split(",") if v.strip() != ""]:
+                rec, res = cpu_baseline(frames_h, gallery, threads=t or None)
+                sweep.append(rec)
+                res0 = res0 or res
+            out["cpu_baseline"] = max(sweep, key=lambda r: r["value"])
+            out["cpu_baseline_sweep"] = [{"cores": r["cores"], "value": r["value"]} for r in sweep]
+            out["oracle_check"] = oracle_check(res0, gpu0, 1e-3)
+            if not out["oracle_check"]["ok"]:
+                fail = "oracle_check failed: the GPU's results for batch 0 differ from the CPU oracle's"
         print(json.dumps(out), flush=True)
+        if fail:
+            print(fail, file=sys.stderr, flush=True)
+            if world > 1 or args.force_exchange:
+                dist.destroy_process_group()
+            sys.exit(4)
     if world > 1 or args.force_exchange:
         dist.barrier()
         dist.destroy_process_group()

@@ -32,7 +32,7 @@ class ConvF8Args(C.Structure):
     _fields_ = [("x8", C.c_void_p), ("w8", C.c_void_p), ("y16", C.c_void_p), ("y8", C.c_void_p),
                 ("oscale", C.c_void_p), ("bias", C.c_void_p), ("slope", C.c_void_p), ("residual", C.c_void_p),
                 ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
-                ("bias_mode", C.c_int), ("y8_mul", C.c_float)]
+                ("bias_mode", C.c_int), ("y8_mul", C.c_float), ("y8_sub", C.c_void_p)]
 
 
 _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
@@ -56,6 +56,8 @@ SIGNATURES = {
     "fr_match_decide": (_I, [_P, _P, _I, _F, _F, _P, _P]),
     "fr_match_pack_candidates": (_I, [_P, _P, _I, _P, _P]),
     "fr_match_reduce_shards": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "fr_exchange_pack_queries": (_I, [_P, _I, _I, _I, _P, _P]),
+    "fr_exchange_counts": (_I, [_P, _I, _I, _I, _P, _P]),
     "fr_gallery_first_above_f32": (_I, [_P, _P, _I, _L, _I, _F, _I, _L, _P, _P, _P, _Z, _P]),
     "fr_cosine_matrix_f32": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "fr_mean_rows_f32": (_I, [_P, _I, _I, _P, _P]),
@@ -63,6 +65,8 @@ SIGNATURES = {
     "fr_conv_sequence": (_I, [C.POINTER(ConvStep), _I, _P]),
     "fr_conv_nhwc_f8": (_I, [C.POINTER(ConvF8Args), _P]),
     "fr_quantize_f16_f8": (_I, [_P, _P, _L, _F, _P]),
+    "fr_quantize_f16_f8_centred": (_I, [_P, _P, _L, _I, _P, _F, _P]),
+    "fr_gptq_round_e4m3": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "fr_conv_splitk_epilogue": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
     "fr_fc_reduce_l2norm": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
     "fr_warp_affine_5pt": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P]),

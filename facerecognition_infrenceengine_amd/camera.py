@@ -25,32 +25,60 @@ logger = logging.getLogger(__name__)
 
 
 class CameraManager:
-    def __init__(self, embedding_manager, processor=None, capture_factory=None, max_wait_s=0.005):
+    def __init__(self, embedding_manager, processor=None, capture_factory=None, max_wait_s=0.005, reopen_after=20,
+                 dead_after=200):
         """``processor``: a ``FaceRecognitionProcessor`` (built lazily from ``embedding_manager`` when None).
         ``max_wait_s``: how long a turn waits for a first frame before it looks at ``running`` again; a turn never
-        waits for slow cameras once it holds a frame (latency stays that of the slowest *present* frame)."""
+        waits for slow cameras once it holds a frame (latency stays that of the slowest *present* frame).
+        ``reopen_after`` / ``dead_after``: consecutive failed reads before a capture is re-opened / given up."""
         self.embedding_manager = embedding_manager
         self.processor = processor
         self.capture_factory = capture_factory
         self.max_wait_s = max_wait_s
+        self.reopen_after, self.dead_after = max(int(reopen_after), 1), max(int(dead_after), 1)
+        self.latest = {}                       # source -> last processed frame (the default consumer's store)
+        self._latest_lock = threading.Lock()
         self.running = False
         self.threads = []
         self.frame_queues, self.result_queue = {}, None
-        self.stats = {"batches": 0, "frames": 0, "dropped_results": 0, "largest_batch": 0}
+        self.stats = {"batches": 0, "frames": 0, "dropped_results": 0, "largest_batch": 0, "dead_sources": []}
 
     # ---- capture side (infrenceServer.py:573-601)
     def capture_frames(self, source, frame_queue):
-        if self.capture_factory is None:
-            raise RuntimeError("CameraManager needs capture_factory=<callable(source) -> capture object>")
+        """The reference retries a failed read at once (:589-592) - in its own OS process.  Here capture is a thread
+        that shares the interpreter with the ONE batching loop feeding the GPU, so a camera that drops (an RTSP
+        disconnect makes read() fail immediately) must not spin: failed reads back off (10 ms doubling to 100 ms, one
+        warning per 5 s), after ``reopen_after`` consecutive failures the capture is re-opened, and after
+        ``dead_after`` the source is marked dead (``stats['dead_sources']``) and its thread ends."""
         cap = self.capture_factory(source)
         logger.info("Camera %s initialized", source)
+        fails, delay, last_warn = 0, 0.01, 0.0
         try:
             while self.running:
                 ok, frame = cap.read()
                 if not ok:
                     if frame is None and getattr(cap, "exhausted", False):
                         break
+                    fails += 1
+                    now = time.monotonic()
+                    if now - last_warn > 5.0:
+                        logger.warning("Camera %s: read failed (%d in a row)", source, fails)
+                        last_warn = now
+                    if fails >= self.dead_after:
+                        logger.error("Camera %s: %d failed reads in a row: giving up on this source", source, fails)
+                        self.stats["dead_sources"].append(source)
+                        break
+                    if fails % self.reopen_after == 0:
+                        try:
+                            cap.release()
+                            cap = self.capture_factory(source)
+                            logger.info("Camera %s re-opened", source)
+                        except Exception as e:                 # stays failed: the next reads back off again
+                            logger.error("Camera %s: re-open failed: %s", source, e)
+                    time.sleep(delay)
+                    delay = min(delay * 2, 0.1)
                     continue
+                fails, delay = 0, 0.01
                 try:
                     frame_queue.put_nowait(frame)          # non-blocking: skip the frame when the queue is full (:595-598)
                 except queue.Full:
@@ -117,10 +145,14 @@ class CameraManager:
     # ---- control (infrenceServer.py:624-679); called by the /api/camera/start|stop routes
     def start_cameras(self, sources, company_id, display=None):
         """Starts the capture threads and the batching loop and returns; processed frames arrive on
-        ``self.result_queue`` as ``(source, frame)``.  ``display(source, frame)``, when given, is called from a
-        consumer thread for every result (the reference's cv2.imshow loop, :648-667)."""
+        ``self.result_queue`` as ``(source, frame)``.  A consumer thread always drains that queue (the reference's
+        cv2.imshow loop, :648-667): it calls ``display(source, frame)`` when given, otherwise it keeps the latest
+        processed frame per source (``latest_frame(source)``) - so the unchanged ``POST /api/camera/start`` route,
+        which passes no display, neither fills the 10-deep queue nor makes the GPU work for dropped results."""
         if self.running:
             return
+        if self.capture_factory is None:
+            raise RuntimeError("CameraManager needs capture_factory=<callable(source) -> capture object>")
         self.running = True
         sources = list(sources)
         self.frame_queues = {s: queue.Queue(maxsize=2) for s in sources}      # :629
@@ -130,15 +162,28 @@ class CameraManager:
             t.start(); self.threads.append(t)
         t = threading.Thread(target=self.process_cameras, args=(sources, company_id), daemon=True)
         t.start(); self.threads.append(t)
-        if display is not None:
-            def show():
-                while self.running:
-                    try:
-                        display(*self.result_queue.get(timeout=1))
-                    except queue.Empty:
-                        continue
-            t = threading.Thread(target=show, daemon=True)
-            t.start(); self.threads.append(t)
+
+        def keep_latest(source, frame):
+            with self._latest_lock:
+                self.latest[source] = frame
+
+        sink = display if display is not None else keep_latest
+
+        def consume():
+            while self.running:
+                try:
+                    sink(*self.result_queue.get(timeout=1))
+                except queue.Empty:
+                    continue
+                except Exception as e:
+                    logger.error("Result consumer failed: %s", e)
+        t = threading.Thread(target=consume, daemon=True)
+        t.start(); self.threads.append(t)
+
+    def latest_frame(self, source):
+        """Last processed frame of ``source`` kept by the default consumer (None before the first result)."""
+        with self._latest_lock:
+            return self.latest.get(source)
 
     def stop_cameras(self):
         self.running = False

@@ -21,7 +21,8 @@
 struct HaloP {
     const half_t* x; const half_t* w; half_t* y;     // F8 variant: x, w are fp8 e4m3 bytes; y (f16) may be NULL
     const float* bias; const float* slope; const half_t* res;
-    const float* oscale; unsigned char* y8; float y8_mul;   // F8: acc * oscale[cout] first; optional fp8 copy of the output * y8_mul
+    const float* oscale; unsigned char* y8; float y8_mul;   // F8: acc * oscale[cout] first; optional fp8 copy of the output: (y - y8_sub[cout]) * y8_mul
+    const float* y8_sub;                                    // per-channel centre of the consumer's input (or NULL)
     int B, H, W, Cin, Cout, bias_mode;
     int TH, tiles_per_img;      // output rows per tile, H / TH
     int G;                      // images per tile (1; 4 at 7x7, where TH = H: a tile = G whole images, each with its own halo)
@@ -553,9 +554,14 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_halo_kernel(HaloP p) {
             for (int e = tid; e < npx * CPR; e += NT) {
                 const int px = e / CPR, cc = e - px * CPR;
                 const half8 h = *reinterpret_cast<const half8*>(ot + px * OP + cc * 8);
+                float4v s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+                if (p.y8_sub) {
+                    s0 = *reinterpret_cast<const float4v*>(p.y8_sub + cout0 + cc * 8);
+                    s1 = *reinterpret_cast<const float4v*>(p.y8_sub + cout0 + cc * 8 + 4);
+                }
                 int2 o;
-                o.x = pack_fp8x4((float)h[0] * p.y8_mul, (float)h[1] * p.y8_mul, (float)h[2] * p.y8_mul, (float)h[3] * p.y8_mul);
-                o.y = pack_fp8x4((float)h[4] * p.y8_mul, (float)h[5] * p.y8_mul, (float)h[6] * p.y8_mul, (float)h[7] * p.y8_mul);
+                o.x = pack_fp8x4(((float)h[0] - s0[0]) * p.y8_mul, ((float)h[1] - s0[1]) * p.y8_mul, ((float)h[2] - s0[2]) * p.y8_mul, ((float)h[3] - s0[3]) * p.y8_mul);
+                o.y = pack_fp8x4(((float)h[4] - s1[0]) * p.y8_mul, ((float)h[5] - s1[1]) * p.y8_mul, ((float)h[6] - s1[2]) * p.y8_mul, ((float)h[7] - s1[3]) * p.y8_mul);
                 *reinterpret_cast<int2*>(p.y8 + (size_t)(m_base + px) * p.Cout + cout0 + cc * 8) = o;
             }
         }
@@ -612,7 +618,7 @@ int fr_conv_halo_try(const fr_conv_args* a, hipStream_t s) {
     HaloP p;
     p.x = (const half_t*)a->x; p.w = (const half_t*)a->w; p.y = (half_t*)a->y;
     p.bias = a->bias; p.slope = a->slope; p.res = (const half_t*)a->residual;
-    p.oscale = nullptr; p.y8 = nullptr; p.y8_mul = 0.f;
+    p.oscale = nullptr; p.y8 = nullptr; p.y8_mul = 0.f; p.y8_sub = nullptr;
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.bias_mode = a->bias_mode;
     p.TH = TH; p.tiles_per_img = a->H / TH; p.G = G;
     p.xbytes = (unsigned)((int64_t)a->B * a->H * a->W * a->Cin * 2);
@@ -679,7 +685,7 @@ extern "C" int fr_conv_nhwc_f8(const fr_conv_f8_args* a, fr_stream_t stream) {
     HaloP p;
     p.x = (const half_t*)a->x8; p.w = (const half_t*)a->w8; p.y = (half_t*)a->y16;
     p.bias = a->bias; p.slope = a->slope; p.res = (const half_t*)a->residual;
-    p.oscale = a->oscale; p.y8 = (unsigned char*)a->y8; p.y8_mul = a->y8_mul;
+    p.oscale = a->oscale; p.y8 = (unsigned char*)a->y8; p.y8_mul = a->y8_mul; p.y8_sub = a->y8_sub;
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.bias_mode = a->bias_mode;
     p.TH = a->H == 14 ? 14 : 7; p.tiles_per_img = a->H / p.TH; p.G = 1;
     p.xbytes = (unsigned)((int64_t)a->B * a->H * a->W * a->Cin);
@@ -693,24 +699,42 @@ extern "C" int fr_conv_nhwc_f8(const fr_conv_f8_args* a, fr_stream_t stream) {
     return FR_OK;
 }
 
-// f16 -> fp8 e4m3 (x * mul, saturating): input of the first fp8 conv of a stage
-__global__ void quantize_f16_f8(const half_t* __restrict__ x, unsigned char* __restrict__ out, int64_t n8, float mul) {
+// f16 -> fp8 e4m3 ((x - sub[channel]) * mul, saturating): input of the first fp8 conv of a chain
+__global__ void quantize_f16_f8(const half_t* __restrict__ x, unsigned char* __restrict__ out, int64_t n8, float mul,
+                                const float* __restrict__ sub, int C8) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         const half8 h = *reinterpret_cast<const half8*>(x + i * 8);
+        float4v s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        if (sub) {
+            const int c = (int)(i % C8) * 8;
+            s0 = *reinterpret_cast<const float4v*>(sub + c);
+            s1 = *reinterpret_cast<const float4v*>(sub + c + 4);
+        }
         int2 o;
-        o.x = pack_fp8x4((float)h[0] * mul, (float)h[1] * mul, (float)h[2] * mul, (float)h[3] * mul);
-        o.y = pack_fp8x4((float)h[4] * mul, (float)h[5] * mul, (float)h[6] * mul, (float)h[7] * mul);
+        o.x = pack_fp8x4(((float)h[0] - s0[0]) * mul, ((float)h[1] - s0[1]) * mul, ((float)h[2] - s0[2]) * mul, ((float)h[3] - s0[3]) * mul);
+        o.y = pack_fp8x4(((float)h[4] - s1[0]) * mul, ((float)h[5] - s1[1]) * mul, ((float)h[6] - s1[2]) * mul, ((float)h[7] - s1[3]) * mul);
         *reinterpret_cast<int2*>(out + i * 8) = o;
     }
+}
+
+static int quantize_launch(const void* x16, void* out8, int64_t n, float mul, const float* sub, int C, fr_stream_t stream) {
+    int64_t blocks = (n / 8 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    quantize_f16_f8<<<(int)blocks, 256, 0, fr_stream(stream)>>>((const half_t*)x16, (unsigned char*)out8, n / 8, mul, sub, C / 8);
+    FR_CHECK_LAUNCH("quantize_f16_f8");
+    return FR_OK;
 }
 
 extern "C" int fr_quantize_f16_f8(const void* x16, void* out8, int64_t n, float mul, fr_stream_t stream) {
     if (n <= 0) return FR_OK;
     FR_REQUIRE(x16 && out8 && n % 8 == 0, "fr_quantize_f16_f8: null pointer or n not a multiple of 8");
-    int64_t blocks = (n / 8 + 255) / 256;
-    if (blocks > 16384) blocks = 16384;
-    quantize_f16_f8<<<(int)blocks, 256, 0, fr_stream(stream)>>>((const half_t*)x16, (unsigned char*)out8, n / 8, mul);
-    FR_CHECK_LAUNCH("quantize_f16_f8");
-    return FR_OK;
+    return quantize_launch(x16, out8, n, mul, nullptr, 8, stream);
+}
+
+extern "C" int fr_quantize_f16_f8_centred(const void* x16, void* out8, int64_t n, int C, const float* sub, float mul,
+                                          fr_stream_t stream) {
+    if (n <= 0) return FR_OK;
+    FR_REQUIRE(x16 && out8 && sub && C > 0 && C % 8 == 0 && n % C == 0, "fr_quantize_f16_f8_centred: bad argument (n %lld, C %d)", (long long)n, C);
+    return quantize_launch(x16, out8, n, mul, sub, C, stream);
 }

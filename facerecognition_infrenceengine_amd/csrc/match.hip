@@ -310,6 +310,46 @@ extern "C" int fr_match_reduce_shards(const int32_t* cand, int R, int n, int q0,
     return FR_OK;
 }
 
+// Exchange glue of the sharded match (distributed.py).  These used to be torch kernels (zeros / slice-assign / fill_ /
+// dtype cast) on the embed stream: arithmetic this library does not build shares no stream with the convs.
+// send f32 [q_max+1][D]: rows [0,F) = Q, rows [F,q_max) = 0, row q_max = (F, 0, 0, ...) - the count rides along.
+__global__ void exchange_pack_queries(const float* __restrict__ Q, int F, int q_max, int D, float* __restrict__ send) {
+    const int64_t n4 = (int64_t)(q_max + 1) * D / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i * 4 / D);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < F) v = reinterpret_cast<const float4*>(Q)[i];
+        else if (row == q_max && i * 4 == (int64_t)row * D) v.x = (float)F;
+        reinterpret_cast<float4*>(send)[i] = v;
+    }
+}
+
+// counts[r] = (int) gathered[r][q_max][0], clamped to [0, q_max]
+__global__ void exchange_counts(const float* __restrict__ gathered, int R, int q_max, int D, int32_t* __restrict__ counts) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float c = gathered[((int64_t)r * (q_max + 1) + q_max) * D];
+    int n = (int)c;
+    counts[r] = n < 0 ? 0 : (n > q_max ? q_max : n);
+}
+
+extern "C" int fr_exchange_pack_queries(const float* Q, int F, int q_max, int D, float* send, fr_stream_t stream) {
+    FR_REQUIRE(send && q_max >= 0 && F >= 0 && F <= q_max && D > 0 && D % 4 == 0 && (Q || F == 0),
+               "fr_exchange_pack_queries: bad argument (F %d q_max %d D %d)", F, q_max, D);
+    const int64_t n4 = (int64_t)(q_max + 1) * D / 4;
+    int blocks = fr_cdiv(n4, 256); if (blocks > 2048) blocks = 2048;
+    exchange_pack_queries<<<blocks, 256, 0, fr_stream(stream)>>>(Q, F, q_max, D, send);
+    FR_CHECK_LAUNCH("exchange_pack_queries");
+    return FR_OK;
+}
+
+extern "C" int fr_exchange_counts(const float* gathered, int R, int q_max, int D, int32_t* counts, fr_stream_t stream) {
+    FR_REQUIRE(gathered && counts && R >= 1 && q_max >= 0 && D > 0, "fr_exchange_counts: bad argument");
+    exchange_counts<<<fr_cdiv(R, 64), 64, 0, fr_stream(stream)>>>(gathered, R, q_max, D, counts);
+    FR_CHECK_LAUNCH("exchange_counts");
+    return FR_OK;
+}
+
 __global__ void f32_to_f16_k(const float* __restrict__ x, half_t* __restrict__ out, int64_t n) {
     int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     for (; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {

@@ -72,7 +72,12 @@ __device__ __forceinline__ int4v sg_pack_f16(const float* q) {
     return __builtin_bit_cast(int4v, h);
 }
 
+// saturating at +-448: past the range the OCP e4m3 conversion produces NaN, and a NaN code fails every '>' of the
+// coarse scan - a non-unit row or query (set_rows(normalise=False), match_device(renormalise=False)) with an element
+// beyond 1.75 (x 256) would silently never reach the exact re-rank
 __device__ __forceinline__ int sg_pack_fp8x4(float a, float b, float c, float d) {
+    a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+    c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
     int v = 0;
     v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
     v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);

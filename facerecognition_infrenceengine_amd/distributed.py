@@ -16,7 +16,8 @@ The reference's only parallelism is one OS process per camera, each scanning the
 
 The arithmetic is injected as an ``ops`` object: ``HipOps`` (the product: libfrhip.so kernels through
 ``GalleryMatcher``; fails without a HIP device) or, in the CPU ``gloo`` tests, an oracle-backed stand-in with
-the same four methods.  This module itself only moves bytes.
+the same six methods.  This module itself only moves bytes: it launches no torch kernel between the embedder's
+output and the ids (zeros / slice-assign / fill_ / casts used to run on the embed stream beside the other pipe's convs).
 
 Query rows travel as f32 (2 KB/row), not f16: the scan's final scores are exact f32 dots of the SAME f32
 query the single-GPU path uses, which is what keeps top-1 ids bit-identical to the CPU loop; at 256 faces
@@ -41,6 +42,21 @@ def pack_candidates(idx, score):
     pair[:, 0] = score.contiguous().view(torch.int32)
     pair[:, 1:] = idx.contiguous().view(torch.int32).view(n, 2)
     return pair
+
+
+def pack_queries(Qn, q_max):
+    """Qn f32 [F,D] -> send f32 [q_max+1, D]: the rows, zero rows up to q_max, and a last row whose first element is
+    F.  Torch form of fr_exchange_pack_queries (CPU gloo tests, cross-check of the kernel)."""
+    F, D = Qn.shape
+    send = torch.zeros((q_max + 1, D), dtype=torch.float32, device=Qn.device)
+    send[:F] = Qn
+    send[q_max:, :1].fill_(float(F))          # (a scalar __setitem__ copies from the host and SYNCHRONISES)
+    return send
+
+
+def gathered_counts(allq, world, q_max):
+    """allq f32 [world*(q_max+1), D] -> int32 [world].  Torch form of fr_exchange_counts."""
+    return allq.view(world, q_max + 1, -1)[:, q_max, 0].to(torch.int32).clamp(0, q_max).contiguous()
 
 
 def reduce_candidates(scores, idx):
@@ -86,6 +102,20 @@ class HipOps:
         """Q: unit query rows f32 [n,512]; returns global rows (shard row + row_lo) or -1."""
         return self.matcher.match_device(Q, renormalise=False, row_offset=self.row_lo, counts=counts, seg_len=seg_len)
 
+    def pack_queries(self, Qn, q_max):
+        send = torch.empty((q_max + 1, Qn.shape[1]), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self.lib.fr_exchange_pack_queries(self._lib.ptr(Qn), Qn.shape[0], q_max, Qn.shape[1], self._lib.ptr(send),
+                                              self._lib.stream_ptr())
+        return send
+
+    def gathered_counts(self, allq, world, q_max):
+        counts = torch.empty(world, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            self.lib.fr_exchange_counts(self._lib.ptr(allq), world, q_max, allq.shape[1], self._lib.ptr(counts),
+                                        self._lib.stream_ptr())
+        return counts
+
     def pack(self, idx, score):
         n = score.shape[0]
         cand = torch.empty((n, 3), dtype=torch.int32, device=self.device)
@@ -105,7 +135,7 @@ class HipOps:
 
 class ShardedGalleryMatcher:
     def __init__(self, ops, q_max, dim=512, group=None, force_exchange=False):
-        """``ops``: renormalise / scan / pack / reduce (``HipOps`` in the product).
+        """``ops``: renormalise / pack_queries / gathered_counts / scan / pack / reduce (``HipOps`` in the product).
         ``force_exchange``: run both collectives even with one rank (rehearses the RCCL path on a 1-GPU box)."""
         self.ops, self.q_max, self.dim, self.group = ops, q_max, dim, group
         self.force_exchange = force_exchange
@@ -121,20 +151,18 @@ class ShardedGalleryMatcher:
         if self.world == 1 and not self.force_exchange:
             return self.ops.scan(Qn)
         dev = Q.device
+        seg = self.q_max + 1
         # (1) gather queries; the count rides in an extra row so it stays ONE collective
-        send = torch.zeros((self.q_max + 1, self.dim), dtype=torch.float32, device=dev)
-        send[:F] = Qn
-        send[self.q_max:, :1].fill_(float(F))     # (a scalar __setitem__ copies from the host and SYNCHRONISES)
-        allq = torch.empty((self.world * (self.q_max + 1), self.dim), dtype=torch.float32, device=dev)
+        send = self.ops.pack_queries(Qn, self.q_max)
+        allq = torch.empty((self.world * seg, self.dim), dtype=torch.float32, device=dev)
         dist.all_gather_into_tensor(allq, send, group=self.group)      # concatenated along dim 0
-        allq = allq.view(self.world, self.q_max + 1, self.dim)
-        counts = allq[:, self.q_max, 0].to(torch.int32).contiguous()   # gathered face counts, on the device
-        # (2) scan the local shard for every gathered query slot (fixed shape; slots >= count are skipped by the scan)
-        flat = allq[:, :self.q_max].reshape(self.world * self.q_max, self.dim)
-        idx, score = self.ops.scan(flat, counts=counts, seg_len=self.q_max)
+        counts = self.ops.gathered_counts(allq, self.world, self.q_max)   # gathered face counts, on the device
+        # (2) scan the local shard for every gathered query slot IN PLACE: a rank's segment is its q_max query slots +
+        # the count row, which is slot q_max >= count, i.e. padding like every slot past the count (skipped by the scan)
+        idx, score = self.ops.scan(allq, counts=counts, seg_len=seg)
         # (3) gather the per-shard candidates and reduce those of the local queries
         n = score.shape[0]
         pair = self.ops.pack(idx, score)
         allp = torch.empty((self.world * n, 3), dtype=torch.int32, device=dev)
         dist.all_gather_into_tensor(allp, pair, group=self.group)
-        return self.ops.reduce(allp, self.world, n, self.rank * self.q_max, F)
+        return self.ops.reduce(allp, self.world, n, self.rank * seg, F)

@@ -9,6 +9,7 @@ detect (MTCNN, HIP) -> align (5-point warp, HIP) -> embed (IResNet on MFMA, HIP)
 step lives in ``gallery.GalleryMatcher``.  There is no CPU path: construction succeeds
 anywhere, ``prepare`` raises without a HIP device.
 """
+import logging
 import os
 import threading
 import warnings
@@ -70,14 +71,23 @@ class FaceAnalysis:
                 det = tuple(weights.load_state(q) for q in ps)
         if rec is None and os.path.isdir(d):              # insightface packs ship the recognition network as ONNX
             from .onnx_import import iresnet_state_from_onnx
+            skipped = []
             for fn in sorted(os.listdir(d)):
                 if fn.endswith(".onnx"):
                     try:
                         st, arch = iresnet_state_from_onnx(os.path.join(d, fn))
-                    except (ValueError, IndexError, KeyError):
-                        continue                           # the pack's detector / landmark / attribute models
+                    except Exception as e:                 # the pack's detector / landmark / attribute models, or a
+                        skipped.append(f"{fn}: {type(e).__name__}: {e}")      # graph this reader cannot map
+                        continue
                     rec, self.arch = {k: torch.from_numpy(v) for k, v in st.items()}, arch
                     break
+            for why in skipped:
+                logging.getLogger(__name__).info("model pack '%s': skipped %s", self.name, why)
+            if rec is None and skipped:
+                # the directory HOLDS .onnx files but none maps onto an ArcFace IResNet: falling back to synthetic
+                # recognition weights here would silently recognise nobody
+                raise _lib.FrError(f"model pack '{self.name}' under {d}: none of its .onnx files is a readable ArcFace "
+                                   "IResNet (" + "; ".join(skipped) + ")")
         self.synthetic = rec is None or det is None
         if self.synthetic:
             missing = " and ".join(w for w, x in (("recognition", rec), ("MTCNN detector", det)) if x is None)
@@ -137,6 +147,7 @@ class FaceAnalysis:
         other.det_kwargs = {**self.det_kwargs, **det_kwargs}
         other.det = MTCNNHIP(*self._det_states, device=self.device, **other.det_kwargs)
         other._use_graphs, other._graphs = False, {}
+        other._shares_rec = self._shares_rec = True          # neither engine may free the shared network's plans
         return other
 
     # ------------------------------------------------------------------ device-side pipeline
@@ -240,6 +251,9 @@ class FaceAnalysis:
         self._use_graphs = bool(on)
         if not on:
             self._graphs = {}
+            if self.rec is not None and not getattr(self, "_shares_rec", False):
+                torch.cuda.synchronize(self.device)          # replays in flight still read the plan buffers
+                self.rec.release_plans()                     # ~90 MB per stream that the dropped graphs kept alive
         return self
 
     def _graph_for(self, shape):

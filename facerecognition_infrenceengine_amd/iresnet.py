@@ -16,7 +16,7 @@ Folding (inference BN):  s = gamma / sqrt(var + eps),  t = beta - mean * s.
            (columns permuted to NHWC order), run split-K on the same MFMA kernel.
 """
 import ctypes
-import os
+import logging
 import threading
 
 import torch
@@ -27,10 +27,12 @@ from .weights import IRESNET_LAYERS, IRESNET_WIDTHS
 BN_EPS = 1e-5
 FC_SPLITK = 28
 # up to this many faces the 3x3 convs run split along K (see IResNetHIP._small_batch_splitk)
-SMALL_BATCH = int(os.environ.get("FR_SMALL_BATCH", "48"))      # measured crossover: 32 faces 2.7 vs 3.3 ms, 64 faces 4.6 vs 3.7 ms
+SMALL_BATCH = 48      # measured crossover: 32 faces 2.7 vs 3.3 ms, 64 faces 4.6 vs 3.7 ms
 # up to this many faces (single frames) every K slice is at most 3 K steps long: a slice's steps are dependent HBM
 # round trips (the weights are cold: 130 MB per forward), so a launch takes ~1.2 us per step + ~3 us
-LOW_BATCH = int(os.environ.get("FR_LOW_BATCH", "8"))
+LOW_BATCH = 8
+# single-frame plans (4 x 12.8 MB of activations + ~40 MB of split-K scratch per HIP stream) are kept for this many streams
+MAX_PLAN_STREAMS = 8
 
 
 def _bn_fold(st, prefix, n, conv=None):
@@ -61,6 +63,49 @@ def f8_eligible(c, H):
     return c.k == 3 and c.stride == 1 and H in (14, 28) and c.cin % 128 == 0 and c.cout % 128 == 0
 
 
+def round_e4m3(t):
+    """Round a float tensor to the nearest OCP e4m3 VALUE (ties to even, saturating at +-448; subnormal step 2^-9) in
+    plain float arithmetic - device- and dtype-independent (the GPTQ loop runs in f64 on the GPU)."""
+    a = t.abs().clamp(max=F8_MAX)
+    _, e = torch.frexp(a.clamp_min(2.0 ** -9))                    # a = m * 2^e, m in [0.5, 1)
+    step = torch.ldexp(torch.ones_like(a), (e - 1).clamp_min(-6) - 3)
+    return torch.copysign(torch.round(a / step) * step, t)
+
+
+def gptq_factor(hm, damp=0.01):
+    """Upper Cholesky factor U of the inverse of the (damped) second-moment matrix hm [K,K], f64."""
+    K = hm.shape[0]
+    hm = hm.double() + damp * hm.diagonal().mean().double() * torch.eye(K, dtype=torch.float64, device=hm.device)
+    return torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(hm)), upper=True).contiguous()
+
+
+def gptq_e4m3_torch(w, hm, sw, block=128, damp=0.01):
+    """GPTQ rounding (Frantar et al. 2022) of folded weights ``w`` [Cout, K] to the per-row e4m3 grid ``sw[co] * e4m3``
+    given the second-moment matrix ``hm`` [K, K] of the conv's (centred) input patches, K order as ``w``'s columns:
+    columns are rounded one after the other and each column's rounding error is pushed onto the columns still to
+    come along the inverse Hessian, so that the OUTPUT error ||(W - Wq) X|| - not the weight error - is what is
+    minimised.  Returns the rounded weights divided by sw (values on the e4m3 grid), f32.  Plain-torch form (blocked):
+    the cross-check of fr_gptq_round_e4m3, which the product uses."""
+    W = w.double().clone()
+    K = W.shape[1]
+    U = gptq_factor(hm, damp)
+    sw = sw.double()
+    Q = torch.empty_like(W)
+    for i0 in range(0, K, block):
+        i1 = min(i0 + block, K)
+        W1, U1 = W[:, i0:i1].clone(), U[i0:i1, i0:i1]
+        E1 = torch.empty_like(W1)
+        for j in range(i1 - i0):
+            q = round_e4m3(W1[:, j] / sw)
+            Q[:, i0 + j] = q
+            err = (W1[:, j] - q * sw) / U1[j, j]
+            W1[:, j:] -= err[:, None] * U1[j, j:][None, :]
+            E1[:, j] = err
+        if i1 < K:
+            W[:, i1:] -= E1 @ U[i0:i1, i1:]
+    return Q.to(torch.float32)
+
+
 def quantise_weights_f8(w):
     """[Cout, K] (f64/f32, folded) -> (uint8 e4m3 bytes [Cout, K], per-output-channel scale sw f32 [Cout]):
     w8 = fp8(w / sw), sw = max|w[co]| / 448."""
@@ -70,13 +115,64 @@ def quantise_weights_f8(w):
     return q.view(torch.uint8).contiguous(), sw
 
 
+def fold_iresnet(state, arch="r100"):
+    """Inference-BN folding of an IResNet state dict in f64 on the host (module docstring).  Pure: no device, no
+    library - ``IResNetHIP`` packs the result for the kernels, ``tools/fp8_sim.py`` replays it on the CPU.
+    Returns {"stem": conv, "blocks": [{"c1", "c2", "sc"}], "fc_w" [512, 49*512] (NHWC K order), "fc_bias"}; a conv is
+    {"w" f64 [Cout,Cin,KH,KW] (stem: packed [64,128]), "bias" (c1: bias9 flattened [9*Cout]), "slope", "cin", "cout",
+    "stride"}."""
+    layers = IRESNET_LAYERS[arch]
+    st = {k: torch.as_tensor(v).detach().to("cpu") for k, v in state.items()}
+    # stem: conv1 + bn1 + prelu, packed K = 16 taps x 8 channels
+    s, t = _bn_fold(st, "bn1", 64, conv="conv1")
+    w = st["conv1.weight"].double() * s[:, None, None, None]
+    wp = torch.zeros(64, 16, 8, dtype=torch.float64)
+    wp[:, :9, :3] = w.permute(0, 2, 3, 1).reshape(64, 9, 3)
+    out = {"stem": {"w": wp.reshape(64, 128), "w4": w, "bias": t, "slope": st["prelu.weight"], "cin": 8, "cout": 64,
+                    "stride": 1}, "blocks": []}
+    cin = 64
+    for li, (n, cout) in enumerate(zip(layers, IRESNET_WIDTHS), start=1):
+        for bi in range(n):
+            p = f"layer{li}.{bi}"
+            stride = 2 if bi == 0 else 1
+            s1, t1 = _bn_fold(st, p + ".bn1", cin)
+            s2, t2 = _bn_fold(st, p + ".bn2", cout, conv=p + ".conv1")
+            s3, t3 = _bn_fold(st, p + ".bn3", cout, conv=p + ".conv2")
+            w1 = st[p + ".conv1.weight"].double()
+            w1f = w1 * s2[:, None, None, None] * s1[None, :, None, None]
+            tap = (w1 * t1[None, :, None, None]).sum(1) * s2[:, None, None]      # [co,kh,kw]
+            valid = {0: [1, 2], 1: [0, 1, 2], 2: [0, 1]}
+            bias9 = torch.empty(3, 3, cout, dtype=torch.float64)
+            for rc in range(3):
+                for cc in range(3):
+                    bias9[rc, cc] = t2 + tap[:, valid[rc]][:, :, valid[cc]].sum((1, 2))
+            c1 = {"w": w1f, "bias": bias9.reshape(9 * cout), "slope": st[p + ".prelu.weight"], "cin": cin,
+                  "cout": cout, "stride": 1}
+            w2f = st[p + ".conv2.weight"].double() * s3[:, None, None, None]
+            c2 = {"w": w2f, "bias": t3, "slope": None, "cin": cout, "cout": cout, "stride": stride}
+            sc = None
+            if bi == 0:
+                sd, td = _bn_fold(st, p + ".downsample.1", cout, conv=p + ".downsample.0")
+                wd = st[p + ".downsample.0.weight"].double() * sd[:, None, None, None]
+                sc = {"w": wd, "bias": td, "slope": None, "cin": cin, "cout": cout, "stride": stride}
+            out["blocks"].append({"c1": c1, "c2": c2, "sc": sc})
+            cin = cout
+    # tail
+    sb, tb = _bn_fold(st, "bn2", 512)
+    sf, tf = _bn_fold(st, "features", 512)
+    W = st["fc.weight"].double().reshape(512, 512, 49)                   # [o, c, hw]
+    out["fc_bias"] = sf * (st["fc.bias"].double() + (W * tb[None, :, None]).sum((1, 2))) + tf
+    out["fc_w"] = (W * sb[None, :, None] * sf[:, None, None]).permute(0, 2, 1).reshape(512, 49 * 512)   # NHWC K order
+    return out
+
+
 class _Conv:
     __slots__ = ("w", "bias", "slope", "cin", "cout", "k", "stride", "pad", "bias_mode", "w32", "w8", "sw", "sx",
-                 "oscale")
+                 "oscale", "mu", "bias8")
 
     def __init__(self, w, bias, slope, cin, cout, k, stride, pad, bias_mode, device):
         self.w = w.to(device)
-        self.w32 = self.w8 = self.sw = self.sx = self.oscale = None      # fp8 form, filled by IResNetHIP.enable_fp8
+        self.w32 = self.w8 = self.sw = self.sx = self.oscale = self.mu = self.bias8 = None      # fp8 form, filled by IResNetHIP.enable_fp8
         self.bias = None if bias is None else bias.to(torch.float32).contiguous().to(device)
         self.slope = None if slope is None else slope.to(torch.float32).contiguous().to(device)
         self.cin, self.cout, self.k, self.stride, self.pad, self.bias_mode = cin, cout, k, stride, pad, bias_mode
@@ -87,98 +183,146 @@ class IResNetHIP:
     f16 [B,112,112,8] (RGB in channels 0..2, (x-127.5)/127.5, rest zero) produced by
     ``fr_warp_affine_5pt`` and returns (embedding, normed_embedding) f32 [B,512] on device."""
 
-    def __init__(self, state, arch="r100", device="cuda:0", max_chunk=256):
+    def __init__(self, state, arch="r100", device="cuda:0", max_chunk=256, small_batch=SMALL_BATCH, low_batch=LOW_BATCH):
+        """``small_batch`` / ``low_batch``: batch-size modes of the split-K single-frame path (module constants above;
+        arguments, not environment variables: the product reads no environment)."""
         _lib.require_gpu()
+        self.small_batch, self.low_batch = int(small_batch), int(low_batch)
         self.lib = _lib.load()
         self.device = torch.device(device)
         self.arch = arch
         self.max_chunk = max_chunk
-        layers = IRESNET_LAYERS[arch]
-        st = {k: torch.as_tensor(v).detach().to("cpu") for k, v in state.items()}
         dev = self.device
-        # stem: conv1 + bn1 + prelu, packed K = 16 taps x 8 channels
-        s, t = _bn_fold(st, "bn1", 64, conv="conv1")
-        w = st["conv1.weight"].double() * s[:, None, None, None]
-        wp = torch.zeros(64, 16, 8, dtype=torch.float64)
-        wp[:, :9, :3] = w.permute(0, 2, 3, 1).reshape(64, 9, 3)
-        self.stem = _Conv(wp.reshape(64, 128).to(torch.float16).contiguous(), t, st["prelu.weight"], 8, 64, 3, 1, 1, 0, dev)
+        f = fold_iresnet(state, arch)
+        self.stem = _Conv(f["stem"]["w"].to(torch.float16).contiguous(), f["stem"]["bias"], f["stem"]["slope"],
+                          8, 64, 3, 1, 1, 0, dev)
         self.blocks = []
-        cin = 64
-        for li, (n, cout) in enumerate(zip(layers, IRESNET_WIDTHS), start=1):
-            for bi in range(n):
-                p = f"layer{li}.{bi}"
-                stride = 2 if bi == 0 else 1
-                s1, t1 = _bn_fold(st, p + ".bn1", cin)
-                s2, t2 = _bn_fold(st, p + ".bn2", cout, conv=p + ".conv1")
-                s3, t3 = _bn_fold(st, p + ".bn3", cout, conv=p + ".conv2")
-                w1 = st[p + ".conv1.weight"].double()
-                w1f = w1 * s2[:, None, None, None] * s1[None, :, None, None]
-                tap = (w1 * t1[None, :, None, None]).sum(1) * s2[:, None, None]      # [co,kh,kw]
-                valid = {0: [1, 2], 1: [0, 1, 2], 2: [0, 1]}
-                bias9 = torch.empty(3, 3, cout, dtype=torch.float64)
-                for rc in range(3):
-                    for cc in range(3):
-                        bias9[rc, cc] = t2 + tap[:, valid[rc]][:, :, valid[cc]].sum((1, 2))
-                c1 = _Conv(_pack_w(w1f), bias9.reshape(9 * cout), st[p + ".prelu.weight"], cin, cout, 3, 1, 1, 1, dev)
-                w2f = st[p + ".conv2.weight"].double() * s3[:, None, None, None]
-                c2 = _Conv(_pack_w(w2f), t3, None, cout, cout, 3, stride, 1, 0, dev)
-                if cin % 128 == 0 and cout % 128 == 0:        # folded f32 weights kept on the host for enable_fp8()
-                    c1.w32 = w1f.permute(0, 2, 3, 1).reshape(cout, -1).to(torch.float32)
-                if stride == 1 and cout % 128 == 0:
-                    c2.w32 = w2f.permute(0, 2, 3, 1).reshape(cout, -1).to(torch.float32)
-                sc = None
-                if bi == 0:
-                    sd, td = _bn_fold(st, p + ".downsample.1", cout, conv=p + ".downsample.0")
-                    wd = st[p + ".downsample.0.weight"].double() * sd[:, None, None, None]
-                    sc = _Conv(_pack_w(wd), td, None, cin, cout, 1, stride, 0, 0, dev)
-                self.blocks.append((c1, c2, sc))
-                cin = cout
-        # tail
-        sb, tb = _bn_fold(st, "bn2", 512)
-        sf, tf = _bn_fold(st, "features", 512)
-        W = st["fc.weight"].double().reshape(512, 512, 49)                   # [o, c, hw]
-        bias = sf * (st["fc.bias"].double() + (W * tb[None, :, None]).sum((1, 2))) + tf
-        Wf = (W * sb[None, :, None] * sf[:, None, None]).permute(0, 2, 1).reshape(512, 49 * 512)   # NHWC K order
-        self.fc_w = Wf.to(torch.float16).contiguous().to(dev)
-        self.fc_bias = bias.to(torch.float32).contiguous().to(dev)
+        for b in f["blocks"]:
+            d1, d2, ds = b["c1"], b["c2"], b["sc"]
+            c1 = _Conv(_pack_w(d1["w"]), d1["bias"], d1["slope"], d1["cin"], d1["cout"], 3, 1, 1, 1, dev)
+            c2 = _Conv(_pack_w(d2["w"]), d2["bias"], None, d2["cin"], d2["cout"], 3, d2["stride"], 1, 0, dev)
+            if d1["cin"] % 128 == 0 and d1["cout"] % 128 == 0:        # folded f32 weights kept on the host for enable_fp8()
+                c1.w32 = d1["w"].permute(0, 2, 3, 1).reshape(d1["cout"], -1).to(torch.float32)
+            if d2["stride"] == 1 and d2["cout"] % 128 == 0:
+                c2.w32 = d2["w"].permute(0, 2, 3, 1).reshape(d2["cout"], -1).to(torch.float32)
+            sc = None
+            if ds is not None:
+                sc = _Conv(_pack_w(ds["w"]), ds["bias"], None, ds["cin"], ds["cout"], 1, ds["stride"], 0, 0, dev)
+            self.blocks.append((c1, c2, sc))
+        self.fc_w = f["fc_w"].to(torch.float16).contiguous().to(dev)
+        self.fc_bias = f["fc_bias"].to(torch.float32).contiguous().to(dev)
         self.flops_per_face = self._count_flops()
         self._plans = {}             # (B, stream) -> prepared fr_conv_sequence of the single-frame forward
         self._plan_bufs = {}         # stream -> (4 activation buffers, split-K scratch) shared by that stream's plans
         self._plan_lock = threading.Lock()       # engines cloned with clone_with() share this network across threads
+        self._plan_limit_logged = False
         self.profile = None          # bench.py: list collecting (kernel variant, flops, ev0, ev1) per conv launch
         self.fp8 = False             # enable_fp8(): eligible body convs run on the fp8 matrix cores
         self._calib = None
 
     # ---- fp8 path (BASELINE config C5)
-    def enable_fp8(self, calib_crops):
-        """Switch the eligible 3x3/s1 body convs (28x28, 14x14; 78 % of the r100 FLOPs) to fr_conv_nhwc_f8.
-        Weights: per-output-channel e4m3 (w / sw[co]).  Activations: per-tensor static scales from ONE f16 forward of
-        ``calib_crops`` (f16 [B,112,112,8], as produced by fr_warp_affine_5pt): sx = 1.5 * absmax / 448.  The
-        residual stream, stem, stride-2 convs, 1x1 shortcuts, the 7x7 stage and the FC stay f16."""
-        assert calib_crops.dtype == torch.float16 and calib_crops.shape[1:] == (112, 112, 8)
-        self.fp8 = False
-        self._calib = {}
-        self.forward(calib_crops.contiguous())
-        calib, self._calib = self._calib, None
-        n = 0
+    def fp8_candidates(self):
+        """[(conv, H)] of the layers fr_conv_nhwc_f8 takes, in network order."""
+        out, hw = [], 112
         for c1, c2, _ in self.blocks:
             for c in (c1, c2):
-                if id(c) in calib and c.w32 is not None:
-                    c.sx = max(calib[id(c)] * F8_MARGIN / F8_MAX, 1e-12)
-                    if c.w8 is None:
-                        w8, sw = quantise_weights_f8(c.w32)
-                        c.w8, c.sw = w8.to(self.device), sw.to(self.device)
-                    c.oscale = (c.sw * c.sx).contiguous()
-                    n += 1
+                if c.w32 is not None and f8_eligible(c, hw):
+                    out.append((c, hw))
+            hw //= c2.stride
+        return out
+
+    def enable_fp8(self, calib_crops, select="accurate", centre=True, gptq=True):
+        """Switch body convs to fr_conv_nhwc_f8 (3x3/s1 at 28x28 and 14x14: up to 82 % of the r100 FLOPs).
+
+        e4m3 carries 3 mantissa bits: every fp8 conv adds rounding noise of ~3 % of its output's random part, from the
+        weights and from the activations in equal shares, and the noise of the convs adds up in the residual stream
+        (measured, tools/fp8_sim.py: 1 - cos of the embedding grows by ~4e-5 per fp8 conv, 3.4e-3 for all 84).  What
+        this method does about it, from ONE f16 calibration forward of ``calib_crops`` (f16 [B,112,112,8]):
+          * ``centre``: a conv's input is rounded as (x - mu[c]) / sx with mu the per-channel calibration mean; the
+            exact term W.mu - which depends on the taps that fall inside the image - joins the 9-class border bias.
+            |x - mu| < |x| on average and e4m3's error is relative: halves both noise shares.
+          * ``gptq``: the weights are rounded column by column with error feedback along the inverse second-moment
+            matrix of the (centred) input patches (``gptq_e4m3``), which removes most of the weight share.
+          * ``select``: "accurate" (default) = every eligible 14x14 conv + the last four eligible 28x28 convs (61 % of
+            the r100 FLOPs; 1 - cos < 1e-3, north_star's bound); "all" = every eligible conv (82 %; ~1.1e-3).
+        Activation scales stay static per tensor: sx = 1.5 * absmax|x - mu| / 448 (e4m3 is a floating format: finer
+        scale granularity buys nothing).  The residual stream, stem, stride-2 convs, 1x1 shortcuts, the 7x7 stage and
+        the FC stay f16."""
+        assert calib_crops.dtype == torch.float16 and calib_crops.shape[1:] == (112, 112, 8)
+        cands = self.fp8_candidates()
+        if select == "all":
+            chosen = [c for c, _ in cands]
+        elif select == "accurate":
+            chosen = [c for c, hw in cands if hw == 14] + [c for c, hw in cands if hw == 28][-4:]
+        else:
+            chosen = [c for i, (c, _) in enumerate(cands) if select(i, len(cands))]
+        self.fp8 = False
+        for c, _ in cands:
+            c.oscale = None
+        self._calib = {"want": {id(c) for c in chosen}, "centre": centre, "gptq": gptq, "stats": {}}
+        self.forward(calib_crops.contiguous())
+        stats, self._calib = self._calib["stats"], None
+        n = 0
+        for c in chosen:
+            st = stats.get(id(c))
+            if st is None:
+                continue
+            c.sx = max(st["absmax"] * F8_MARGIN / F8_MAX, 1e-12)
+            c.mu = st["mu"]
+            w8, sw = quantise_weights_f8(c.w32)
+            if st.get("wq") is not None:                  # GPTQ-rounded values on the same per-row grid
+                w8 = st["wq"].cpu().to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+            c.w8, c.sw = w8.to(self.device), sw.to(self.device)
+            c.oscale = (c.sw * c.sx).contiguous()
+            # exact W.mu through the zero padding: 9 border classes (c1's bias is one already; c2's plain bias widens)
+            base = c.bias.double().cpu()
+            base = base.reshape(3, 3, c.cout) if c.bias_mode == 1 else base[None, None, :].expand(3, 3, c.cout)
+            tap = (c.w32.double().reshape(c.cout, 9, c.cin) * (c.mu.double().cpu()[None, None, :] if c.mu is not None else 0.0)).sum(2)
+            tap = tap.reshape(c.cout, 3, 3)
+            valid = {0: [1, 2], 1: [0, 1, 2], 2: [0, 1]}
+            b9 = torch.empty(3, 3, c.cout, dtype=torch.float64)
+            for rc in range(3):
+                for cc in range(3):
+                    b9[rc, cc] = base[rc, cc] + tap[:, valid[rc]][:, :, valid[cc]].sum((1, 2))
+            c.bias8 = b9.reshape(9 * c.cout).to(torch.float32).contiguous().to(self.device)
+            n += 1
         self.fp8 = n > 0
         return n
 
-    def _conv_f8(self, x8, c, B, H, W, residual=None, want16=True, y8_mul=None):
+    def _calib_observe(self, c, x, H):
+        """calibration forward: statistics of the tensor ``x`` (f16 NHWC) an fp8 candidate reads"""
+        cal = self._calib
+        if cal is None or id(c) not in cal["want"] or not f8_eligible(c, H) or c.w32 is None:
+            return
+        xf = x.float()
+        mu = xf.mean(dim=(0, 1, 2)) if cal["centre"] else None
+        xc = xf - mu if mu is not None else xf
+        st = {"absmax": float(xc.abs().max()), "mu": mu.contiguous() if mu is not None else None, "wq": None}
+        if cal["gptq"]:
+            import torch.nn.functional as F
+            P = F.unfold(xc.permute(0, 3, 1, 2), 3, padding=1)                  # [B, Cin*9 (ci, kh, kw), L]
+            P = P.permute(1, 0, 2).reshape(P.shape[1], -1)
+            hm = (P @ P.t()) / P.shape[1]
+            del P
+            perm = (torch.arange(c.cin, device=x.device)[None, :] * 9 + torch.arange(9, device=x.device)[:, None]).reshape(-1)
+            hm = hm[perm][:, perm]                                               # (tap, ci): the column order of w32
+            w = c.w32.to(x.device)
+            sw = (w.abs().amax(dim=1) / F8_MAX).clamp_min(1e-30).contiguous()
+            U = gptq_factor(hm)
+            wd = w.double().contiguous()
+            st["wq"] = torch.empty(w.shape, dtype=torch.float32, device=x.device)
+            self.lib.fr_gptq_round_e4m3(_lib.ptr(wd), _lib.ptr(U), _lib.ptr(sw), _lib.ptr(st["wq"]), w.shape[0], w.shape[1],
+                                        _lib.stream_ptr())
+        cal["stats"][id(c)] = st
+
+    def _conv_f8(self, x8, c, B, H, W, residual=None, want16=True, nxt=None):
+        """``nxt``: the fp8 conv that reads this one's output (its fp8 copy is written centred and scaled for it)"""
         y16 = torch.empty((B, H, W, c.cout), dtype=torch.float16, device=self.device) if want16 else None
-        y8 = torch.empty((B, H, W, c.cout), dtype=torch.uint8, device=self.device) if y8_mul is not None else None
+        y8 = torch.empty((B, H, W, c.cout), dtype=torch.uint8, device=self.device) if nxt is not None else None
         a = _lib.ConvF8Args(_lib.ptr(x8), _lib.ptr(c.w8), _lib.ptr(y16), _lib.ptr(y8), _lib.ptr(c.oscale),
-                            _lib.ptr(c.bias), _lib.ptr(c.slope), _lib.ptr(residual), B, H, W, c.cin, c.cout,
-                            c.bias_mode, float(y8_mul or 0.0))
+                            _lib.ptr(c.bias8), _lib.ptr(c.slope), _lib.ptr(residual), B, H, W, c.cin, c.cout,
+                            1, float(1.0 / nxt.sx) if nxt is not None else 0.0,
+                            _lib.ptr(nxt.mu) if nxt is not None else None)
         if self.profile is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -190,9 +334,14 @@ class IResNetHIP:
             self.lib.fr_conv_nhwc_f8(ctypes.byref(a), _lib.stream_ptr())
         return y16, y8
 
-    def _quantise(self, x16, mul):
+    def _quantise(self, x16, c):
+        """fp8 input of conv ``c`` from an f16 tensor: (x - mu[channel]) / sx, saturating"""
         out = torch.empty(x16.shape, dtype=torch.uint8, device=self.device)
-        self.lib.fr_quantize_f16_f8(_lib.ptr(x16), _lib.ptr(out), x16.numel(), float(mul), _lib.stream_ptr())
+        if c.mu is not None:
+            self.lib.fr_quantize_f16_f8_centred(_lib.ptr(x16), _lib.ptr(out), x16.numel(), c.cin, _lib.ptr(c.mu),
+                                                float(1.0 / c.sx), _lib.stream_ptr())
+        else:
+            self.lib.fr_quantize_f16_f8(_lib.ptr(x16), _lib.ptr(out), x16.numel(), float(1.0 / c.sx), _lib.stream_ptr())
         return out
 
     def _count_flops(self):
@@ -213,12 +362,12 @@ class IResNetHIP:
         along K into slices that run side by side, followed by ``fr_conv_splitk_epilogue``.  The slice count
         depends on the layer and on the MODE only (B <= LOW_BATCH: slices of 3 K steps; B <= SMALL_BATCH: of 9), so
         results do not depend on the batch size inside a mode (between modes they differ by f32 summation order)."""
-        if B > SMALL_BATCH or c.k != 3 or c.cin % 64:
+        if B > self.small_batch or c.k != 3 or c.cin % 64:
             return 1
         nk = 9 * c.cin // 64
         if nk < 18:                  # Cin = 64 (the 112x112 / 56x56 layers): one pass
             return 1
-        if B <= LOW_BATCH:
+        if B <= self.low_batch:
             return -(-nk // 3)
         return min(8, nk // 9)
 
@@ -287,6 +436,15 @@ class IResNetHIP:
             hw = ho
         return n
 
+    def release_plans(self):
+        """Drop every prepared single-frame plan and its per-stream buffers (they are otherwise kept for the life of
+        the network: a captured HIP graph may replay them).  Call only when no captured graph of this network is
+        alive - ``FaceAnalysis.enable_graphs(False)`` does, after dropping its graphs."""
+        with self._plan_lock:
+            self._plans.clear()
+            self._plan_bufs.clear()
+            self._plan_limit_logged = False
+
     def _plan(self, B):
         """Up to LOW_BATCH faces the forward is ~200 launches of a few microseconds each and the Python / ctypes work
         per launch (argument structs, allocations, stream look-ups) is what the GPU waits for.  The same launch
@@ -303,11 +461,16 @@ class IResNetHIP:
         # (never freed: a captured HIP graph may hold them); past 8 streams, launch by launch
         shared = self._plan_bufs.get(sid)
         if shared is None:
-            if len(self._plan_bufs) >= 8:
+            if len(self._plan_bufs) >= MAX_PLAN_STREAMS:
+                if not self._plan_limit_logged:
+                    self._plan_limit_logged = True
+                    logging.getLogger(__name__).warning(
+                        "IResNetHIP: single-frame plans exist for %d streams already; further streams run the conv stack "
+                        "launch by launch (slower single-frame latency).  release_plans() frees them.", MAX_PLAN_STREAMS)
                 return None
             shared = self._plan_bufs[sid] = (
-                [torch.empty(LOW_BATCH * 112 * 112 * 64, dtype=torch.float16, device=dev) for _ in range(4)],
-                torch.empty(self._plan_partial_floats(LOW_BATCH), dtype=torch.float32, device=dev))
+                [torch.empty(self.low_batch * 112 * 112 * 64, dtype=torch.float16, device=dev) for _ in range(4)],
+                torch.empty(self._plan_partial_floats(self.low_batch), dtype=torch.float32, device=dev))
         bufs, partial = shared
         steps, part_floats = [], 0
 
@@ -354,7 +517,7 @@ class IResNetHIP:
     def _forward_chunk(self, x, emb, normed, taps):
         B = x.shape[0]
         plan = None
-        if B <= LOW_BATCH and taps is None and self.profile is None and self._calib is None and not self.fp8:
+        if B <= self.low_batch and taps is None and self.profile is None and self._calib is None and not self.fp8:
             with self._plan_lock:
                 plan = self._plan(B)
         if plan is not None:
@@ -371,17 +534,14 @@ class IResNetHIP:
         h8 = None                                  # fp8 copy of h, scaled for the conv that will read it (or None)
         nb = len(self.blocks)
         for bi_, (c1, c2, sc) in enumerate(self.blocks):
-            if self._calib is not None:            # enable_fp8(): absmax of the tensors the eligible convs read
-                if f8_eligible(c1, H):
-                    self._calib[id(c1)] = max(self._calib.get(id(c1), 0.0), float(h.abs().max()))
-            f1 = self.fp8 and c1.oscale is not None and f8_eligible(c1, H)
-            f2 = self.fp8 and c2.oscale is not None and f8_eligible(c2, H)
+            self._calib_observe(c1, h, H)              # enable_fp8(): statistics of the tensors the candidates read
+            f1 = self.fp8 and c1.oscale is not None
+            f2 = self.fp8 and c2.oscale is not None
             mid8 = None
             if f1:
                 if h8 is None:
-                    h8 = self._quantise(h, 1.0 / c1.sx)
-                mid, mid8 = self._conv_f8(h8, c1, B, H, W, want16=not f2 or taps is not None,
-                                          y8_mul=(1.0 / c2.sx) if f2 else None)
+                    h8 = self._quantise(h, c1)
+                mid, mid8 = self._conv_f8(h8, c1, B, H, W, want16=not f2 or taps is not None, nxt=c2 if f2 else None)
             else:
                 mid, _, _ = self._conv(h, c1, B, H, W)
             if sc is not None:
@@ -391,15 +551,13 @@ class IResNetHIP:
                 short, _, _ = self._conv(h, sc, B, H, W)
             else:
                 short = h
-            if self._calib is not None and f8_eligible(c2, H):
-                self._calib[id(c2)] = max(self._calib.get(id(c2), 0.0), float(mid.abs().max()))
+            self._calib_observe(c2, mid, H)
             if f2:
                 if mid8 is None:
-                    mid8 = self._quantise(mid, 1.0 / c2.sx)
+                    mid8 = self._quantise(mid, c2)
                 nxt = self.blocks[bi_ + 1][0] if bi_ + 1 < nb else None
-                nf1 = nxt is not None and nxt.oscale is not None and f8_eligible(nxt, H)
-                h, h8 = self._conv_f8(mid8, c2, B, H, W, residual=short, want16=True,
-                                      y8_mul=(1.0 / nxt.sx) if nf1 else None)
+                nf1 = nxt is not None and nxt.oscale is not None
+                h, h8 = self._conv_f8(mid8, c2, B, H, W, residual=short, want16=True, nxt=nxt if nf1 else None)
             else:
                 h, H, W = self._conv(mid, c2, B, H, W, residual=short)
                 h8 = None

@@ -72,7 +72,7 @@ _DTYPES = {1: np.float32, 10: np.float16, 11: np.float64, 6: np.int32, 7: np.int
 
 
 def _tensor(buf):
-    dims, dtype, name, raw, floats, int64s = [], 1, "", None, [], []
+    dims, dtype, name, raw, floats, int64s, int32s, external = [], 1, "", None, [], [], [], False
     for f, wt, v in _fields(buf):
         if f == 1:
             dims += [_signed(x) for x in _packed_varints(v, wt)]
@@ -84,16 +84,23 @@ def _tensor(buf):
             raw = bytes(v)
         elif f == 4:                                    # float_data, packed or one fixed32 per element
             floats.append(bytes(v))
+        elif f == 5:                                    # int32_data: int32 payloads, and float16 as uint16 bit patterns
+            int32s += [_signed(x) for x in _packed_varints(v, wt)]
         elif f == 7:
             int64s += [_signed(x) for x in _packed_varints(v, wt)]
-        elif f == 14:
-            raise ValueError(f"initializer {name!r} stores its data in an external file (not supported)")
+        elif f == 14:                                   # data_location: 0 = DEFAULT (legal when written explicitly), 1 = EXTERNAL
+            external = v == 1
+    if external:
+        raise ValueError(f"initializer {name!r} stores its data in an external file (not supported)")
     if dtype not in _DTYPES:
         raise ValueError(f"initializer {name!r}: unsupported ONNX data type {dtype}")
     if raw is not None:
         a = np.frombuffer(raw, dtype=np.dtype(_DTYPES[dtype]).newbyteorder("<"))
     elif floats:
         a = np.frombuffer(b"".join(floats), dtype="<f4")
+    elif int32s:
+        a = np.asarray(int32s, dtype=np.int64)
+        a = a.astype(np.uint16).view(np.float16) if dtype == 10 else a.astype(np.int32)
     else:
         a = np.asarray(int64s, dtype=np.int64)
     return name, a.astype(_DTYPES[dtype]).reshape(dims)

@@ -105,6 +105,12 @@ int fr_match_decide(const int64_t* idx, const float* score, int F, float thr, fl
 int fr_match_pack_candidates(const int64_t* idx, const float* score, int n, int32_t* cand, fr_stream_t stream);
 int fr_match_reduce_shards(const int32_t* cand_all, int R, int n, int q0, int F, int64_t* out_idx,
                            float* out_score, fr_stream_t stream);
+/*      Exchange buffers of the same step: send f32 [q_max+1][D] = the rank's F unit query rows, zero rows up to q_max,
+ *      and one trailing row whose first element is F (the face count rides in the one all-gather); after the gather
+ *      (f32 [R][q_max+1][D]) counts[r] = that element of rank r's block.  The scan then walks the gathered buffer in
+ *      place with seg_len = q_max + 1: the count row is slot q_max >= count, i.e. padding. */
+int fr_exchange_pack_queries(const float* Q, int F, int q_max, int D, float* send, fr_stream_t stream);
+int fr_exchange_counts(const float* gathered, int R, int q_max, int D, int32_t* counts, fr_stream_t stream);
 
 
 /* ------------------------------------------------- enrolment / clustering consumers of the scan ----
@@ -147,17 +153,29 @@ int fr_conv_nhwc_f16(const fr_conv_args* args, fr_stream_t stream);
  * v_mfma_scale_f32_16x16x128_f8f6f4.  x8: OCP fp8 e4m3 NHWC [B,H,W,Cin] = x / sx; w8: e4m3 [Cout][9*Cin] =
  * w / sw[cout] (per-output-channel); oscale[cout] = sw[cout] * sx dequantises the f32 accumulator, then the f16
  * kernel's epilogue: + bias (or 9-class border bias) -> PReLU -> + residual (f16) -> one rounding.  Outputs:
- * y16 (f16 NHWC, may be NULL) and/or y8 = fp8(y * y8_mul) (the next conv's input, may be NULL).
+ * y16 (f16 NHWC, may be NULL) and/or y8 = fp8((y - y8_sub[cout]) * y8_mul) (the next conv's input, may be NULL;
+ * y8_sub: f32 [Cout] per-channel centre the CONSUMER subtracts from its input before rounding - its W.centre term,
+ * which depends on which taps fall inside the image, lives in the consumer's 9-class border bias - or NULL = 0).
  * Cin % 128 == 0, Cout % 128 == 0. */
 typedef struct {
     const void* x8; const void* w8; void* y16; void* y8;
     const float* oscale; const float* bias; const float* slope; const void* residual;
     int B, H, W, Cin, Cout, bias_mode;
     float y8_mul;
+    const float* y8_sub;
 } fr_conv_f8_args;
 int fr_conv_nhwc_f8(const fr_conv_f8_args* args, fr_stream_t stream);
 /* out8 = fp8_e4m3(x16 * mul), saturating at +-448; n % 8 == 0 (input of a stage's first fp8 conv) */
 int fr_quantize_f16_f8(const void* x16, void* out8, int64_t n, float mul, fr_stream_t stream);
+/* out8 = fp8_e4m3((x16 - sub[i % C]) * mul): the same with a per-channel centre (NHWC, C channels innermost; n % C == 0) */
+int fr_quantize_f16_f8_centred(const void* x16, void* out8, int64_t n, int C, const float* sub, float mul,
+                               fr_stream_t stream);
+/* Calibration-time weight rounding for fr_conv_nhwc_f8 (GPTQ, Frantar et al. 2022): W f64 [rows][K] folded weights,
+ * U f64 [K][K] = upper Cholesky factor of the inverse of the second-moment matrix of the conv's input patches (K order
+ * as W's columns), sw f32 [rows] the per-row scale.  Q f32 [rows][K] receives values ON THE e4m3 GRID (w8 = Q exactly):
+ * column k is rounded to the nearest sw * e4m3 value (ties to even, saturating) and its error is pushed onto the
+ * columns still to come along row k of U, so that the conv OUTPUT error is what is minimised.  K <= 8192. */
+int fr_gptq_round_e4m3(const double* W, const double* U, const float* sw, float* Q, int rows, int K, fr_stream_t stream);
 /* Split-K tail of an ordinary conv (small batches): y = epi(sum_z partial[z]) with the epilogue of fr_conv_nhwc_f16
  * (bias or 9-class border bias, PReLU, residual, one rounding to f16).  partial: f32 [splitk][M][Cout]. */
 int fr_conv_splitk_epilogue(const float* partial, int splitk, int M, int Cout, int Ho, int Wo,

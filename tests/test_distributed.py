@@ -17,7 +17,7 @@ def _free_port():
 
 
 class OracleOps:
-    """CPU stand-in for distributed.HipOps: the oracle's arithmetic behind the same four methods, so the exchange
+    """CPU stand-in for distributed.HipOps: the oracle's arithmetic behind the same six methods, so the exchange
     logic (padding, counts, packing, reduce over shards) is what these gloo tests exercise."""
 
     def __init__(self, shard, lo):
@@ -28,7 +28,10 @@ class OracleOps:
         return torch.from_numpy(np.stack([omatch.renormalise(r) for r in q]).astype(np.float32)) if len(q) else Q.clone()
 
     def scan(self, Q, counts=None, seg_len=0):
-        q = Q.numpy()
+        q = Q.numpy().copy()
+        if counts is not None:                                    # padding slots (incl. the count row) are never scanned
+            pad = (np.arange(len(q)) % seg_len) >= counts.numpy()[np.arange(len(q)) // seg_len]
+            q[pad] = 0
         assert not np.isnan(q).any(), "padding rows must not be divided by their norm"
         idx, score = omatch.match_rows_fast(q, self.shard) if len(self.shard) else (
             np.full(len(q), -1, np.int64), np.full(len(q), -1, np.float32))
@@ -37,6 +40,14 @@ class OracleOps:
             pad = (np.arange(len(q)) % seg_len) >= counts.numpy()[np.arange(len(q)) // seg_len]
             idx[pad], score = -1, np.where(pad, np.float32(-1), score)
         return torch.from_numpy(idx), torch.from_numpy(score.astype(np.float32))
+
+    def pack_queries(self, Qn, q_max):
+        from facerecognition_infrenceengine_amd.distributed import pack_queries
+        return pack_queries(Qn, q_max)
+
+    def gathered_counts(self, allq, world, q_max):
+        from facerecognition_infrenceengine_amd.distributed import gathered_counts
+        return gathered_counts(allq, world, q_max)
 
     def pack(self, idx, score):
         from facerecognition_infrenceengine_amd.distributed import pack_candidates

@@ -185,22 +185,41 @@ def test_detector_is_bit_stable_beside_the_embedder(app):
     from make_golden import synth_frame
     batches = [torch.from_numpy(np.ascontiguousarray(np.stack([synth_frame(240, 320, s + k) for s in (10, 20)]))).cuda()
                for k in range(3)]
+    from facerecognition_infrenceengine_amd.distributed import HipOps
+    from facerecognition_infrenceengine_amd.gallery import GalleryMatcher
     crops = (torch.rand((64, 112, 112, 8), device="cuda") * 2 - 1).half()
     crops[..., 3:] = 0
     want = [app.det.detect_batch(b) for b in batches]
     emb0 = app.rec.forward(crops)[0].clone()
+    # the sharded match's exchange runs on the embed stream too: its glue and arithmetic are libfrhip.so kernels
+    # (no torch arithmetic beside the convs); one rank's worth of it here, the two all-gathers being byte moves
+    gm = GalleryMatcher("cuda:0")
+    gm.set_rows(range(4096), torch.randn((4096, 512), device="cuda"), normalise=True)
+    ops = HipOps(gm, 0)
+
+    def exchange(e):
+        Qn = ops.renormalise(e)
+        allq = ops.pack_queries(Qn, 64)
+        cnt = ops.gathered_counts(allq, 1, 64)
+        idx, score = ops.scan(allq, counts=cnt, seg_len=65)
+        return ops.reduce(ops.pack(idx, score), 1, 65, 0, 64)
+    idx0, score0 = exchange(emb0)
+    idx0, score0 = idx0.clone(), score0.clone()
     torch.cuda.synchronize()
     s_det, s_emb = torch.cuda.Stream(), torch.cuda.Stream()
     for rep in range(8):
-        got, embs = [], []
+        got, embs, ids = [], [], []
         for b in batches:
             with torch.cuda.stream(s_emb):
                 embs.append(app.rec.forward(crops)[0])
+                ids.append(exchange(embs[-1]))
             with torch.cuda.stream(s_det):
                 got.append(app.det.detect_batch(b))
         torch.cuda.synchronize()
         for e in embs:
             assert torch.equal(e, emb0)
+        for i, sc in ids:
+            assert torch.equal(i, idx0) and torch.equal(sc, score0)
         for w, g in zip(want, got):
             assert torch.equal(w[3], g[3])
             cap = w[0].shape[1]
@@ -456,6 +475,52 @@ def test_eight_frame_batch_slot_path_vs_oracle(app):
             cos = (e * oemb[:n]).sum(1) / (np.linalg.norm(e, axis=1) * np.linalg.norm(oemb[:n], axis=1))
             assert (1 - cos).max() < 1e-3, (i, cos)
     assert total >= 4
+
+
+def test_bench_geometry_1080p_batch_two_streams_vs_oracle(app):
+    """What bench.py times, at its own geometry: a batch of full-HD frames through the sync-free slot path with the
+    detector on its own HIP stream beside the previous call's embed convs (det_stream=...), every frame against the
+    CPU oracle: boxes, scores, landmarks, embeddings, and top-1 ids against a gallery with planted rows."""
+    from facerecognition_infrenceengine_amd.gallery import GalleryMatcher
+    from make_golden import synth_frame
+    frs = np.ascontiguousarray(np.stack([synth_frame(1080, 1920, 60 + i) for i in range(4)]))
+    dev = torch.from_numpy(frs).cuda()
+    s_det, s_emb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s_emb):
+        app.detect_embed_slots(dev, det_stream=s_det)            # a previous step in flight: its convs overlap ...
+        r = app.detect_embed_slots(dev, det_stream=s_det)        # ... this step's detector
+    torch.cuda.synchronize()
+    counts = r["counts"].cpu().numpy()
+    cap = r["bbox"].shape[1]
+    emb = r["embedding"].cpu().numpy().reshape(4, cap, 512)
+    nrm = r["normed_embedding"].cpu().numpy().reshape(4, cap, 512)
+    rng = np.random.default_rng(9)
+    G = rng.standard_normal((10_000, 512)).astype(np.float32)
+    oracle_emb, queries, planted = [], [], []
+    for i in range(4):
+        ob, os_, ok, oemb = oracle_pipeline(frs[i])
+        n = min(len(os_), cap)
+        assert counts[i] == n >= 1
+        np.testing.assert_allclose(r["bbox"][i, :n].cpu().numpy(), ob[:n], atol=1e-2)
+        np.testing.assert_allclose(r["det_score"][i, :n].cpu().numpy(), os_[:n], atol=5e-5)
+        np.testing.assert_allclose(r["kps"][i, :n].cpu().numpy(), ok[:n], atol=1e-2)
+        e = emb[i, :n]
+        cos = (e * oemb[:n]).sum(1) / (np.linalg.norm(e, axis=1) * np.linalg.norm(oemb[:n], axis=1))
+        assert (1 - cos).max() < 1e-3, (i, cos)
+        for j in range(n):
+            row = int(rng.integers(0, 10_000))
+            while row in planted:
+                row = int(rng.integers(0, 10_000))
+            planted.append(row)
+            G[row] = oemb[j] / np.linalg.norm(oemb[j]) + 0.02 * rng.standard_normal(512).astype(np.float32)
+            oracle_emb.append(oemb[j]); queries.append(nrm[i, j])
+    G /= np.linalg.norm(G, axis=1, keepdims=True)
+    m = GalleryMatcher("cuda:0")
+    m.set_rows(list(range(10_000)), G, normalise=False)
+    ids, score, idx = m.match(np.stack(queries))
+    oi, _ = omatch.match_rows_fast(np.stack([omatch.renormalise(e / np.linalg.norm(e)) for e in oracle_emb]), G)
+    assert np.array_equal(idx, oi)                               # identical top-1 ids vs the oracle's own embeddings
 
 
 def test_camera_batcher_equals_per_frame_recognition(app):

@@ -164,7 +164,7 @@ def test_prepared_sequence_equals_launch_by_launch(r100, monkeypatch):
     for B in (1, 3, 8):
         xa = nchw_to_nhwc8(torch.rand((B, 3, 112, 112), generator=g) * 2 - 1)
         with monkeypatch.context() as m:
-            m.setattr(iresnet, "LOW_BATCH", 0)                  # no plan: launch by launch (slice counts follow LOW_BATCH too)
+            m.setattr(r100, "low_batch", 0)                     # no plan: launch by launch (slice counts follow low_batch too)
             m.setattr(iresnet.IResNetHIP, "_small_batch_splitk", lambda self, c, Bn, f=iresnet.IResNetHIP._small_batch_splitk:
                       _sk_low(c))
             want, _ = r100.forward(xa)
@@ -284,26 +284,105 @@ def test_quantize_f16_f8_matches_torch(lib):
     assert torch.equal(got, want)
 
 
+def _structured_crops(n, seed):
+    """n synthetic 112x112 crops with image-like statistics (low-pass + noise), NCHW f32 in (x - 127.5) / 127.5"""
+    g = torch.Generator().manual_seed(seed)
+    lo = torch.rand((n, 3, 14, 14), generator=g)
+    x = (F.interpolate(lo, (112, 112), mode="bicubic", align_corners=False) * 0.7
+         + 0.3 * torch.rand((n, 3, 112, 112), generator=g)).clamp(0, 1)
+    return ((x * 255).round() - 127.5) / 127.5
+
+
+def test_quantize_f16_f8_centred_matches_torch(lib):
+    from facerecognition_infrenceengine_amd import _lib
+    g = torch.Generator().manual_seed(4)
+    C = 128
+    x = (torch.randn((50, C), generator=g) * 30).to(torch.float16)
+    mu = torch.randn(C, generator=g) * 10
+    xd, md = x.cuda(), mu.cuda()
+    out = torch.empty(x.shape, dtype=torch.uint8, device="cuda")
+    lib.fr_quantize_f16_f8_centred(_lib.ptr(xd), _lib.ptr(out), x.numel(), C, _lib.ptr(md), 0.7, _lib.stream_ptr())
+    got = out.cpu().view(torch.float8_e4m3fn).float()
+    want = _f8((x.float() - mu[None, :]) * 0.7).float()
+    assert torch.equal(got, want)
+
+
+def test_conv_f8_centred_output_copy(lib):
+    """y8 = fp8((y - y8_sub[cout]) * y8_mul): the producer writes its consumer's centred input"""
+    from facerecognition_infrenceengine_amd import _lib
+    g = torch.Generator().manual_seed(9)
+    B, H, C = 2, 14, 256
+    x8 = _f8(torch.randn((B, H, H, C), generator=g) * 40)
+    w = torch.randn((C, 9 * C), generator=g) * (2.0 / (9 * C)) ** 0.5
+    sw = w.abs().amax(1) / 448
+    w8 = _f8(w / sw[:, None])
+    sub = torch.randn(C, generator=g) * 0.5
+    xd, wd = x8.view(torch.uint8).cuda(), w8.view(torch.uint8).cuda()
+    osc = (sw * 0.037).float().cuda()
+    y16 = torch.empty((B, H, H, C), dtype=torch.float16, device="cuda")
+    y8 = torch.empty((B, H, H, C), dtype=torch.uint8, device="cuda")
+    subd = sub.cuda()
+    a = _lib.ConvF8Args(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y16), _lib.ptr(y8), _lib.ptr(osc), None, None, None,
+                        B, H, H, C, C, 0, 3.1, _lib.ptr(subd))
+    lib.fr_conv_nhwc_f8(ctypes.byref(a), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    want = _f8((y16.float().cpu() - sub[None, None, None, :]) * 3.1).float()       # from the kernel's own f16 output: exact
+    assert torch.equal(y8.cpu().view(torch.float8_e4m3fn).float(), want)
+
+
+def test_gptq_kernel_equals_torch_form_and_beats_nearest_rounding(lib):
+    """fr_gptq_round_e4m3 == the plain-torch GPTQ loop (same arithmetic, f64), its values lie on the e4m3 grid, and on
+    correlated inputs its OUTPUT error is below round-to-nearest's (the point of the method)."""
+    from facerecognition_infrenceengine_amd import _lib
+    from facerecognition_infrenceengine_amd.iresnet import gptq_e4m3_torch, gptq_factor, round_e4m3
+    g = torch.Generator().manual_seed(12)
+    rows, K, n = 24, 384, 4000
+    mix = torch.randn((K, K), generator=g) * 0.15 + torch.eye(K)
+    X = (torch.randn((n, K), generator=g) @ mix).cuda()                           # correlated "patches"
+    hm = (X.t() @ X) / n
+    w = (torch.randn((rows, K), generator=g) * 0.05).cuda()
+    sw = (w.abs().amax(1) / 448).contiguous()
+    U = gptq_factor(hm)
+    q = torch.empty((rows, K), dtype=torch.float32, device="cuda")
+    wd = w.double().contiguous()
+    lib.fr_gptq_round_e4m3(_lib.ptr(wd), _lib.ptr(U), _lib.ptr(sw), _lib.ptr(q), rows, K, _lib.stream_ptr())
+    ref = gptq_e4m3_torch(w, hm, sw)
+    assert (q != ref).float().mean().item() < 2e-3          # f64 both; a column on a rounding tie may differ by summation order
+    assert torch.equal(round_e4m3(q), q) and float(q.abs().max()) <= 448
+    rne = round_e4m3(w / sw[:, None])
+    err = lambda z: float(((z * sw[:, None] - w) @ X.t()).pow(2).mean())           # noqa: E731
+    assert err(q) < 0.8 * err(rne), (err(q), err(rne))
+
+
 def test_r100_fp8_embedding_vs_golden(golden):
-    """The fp8 path against the fp32 oracle (r100_kat.npz): states the achieved 1 - cos.  north_star's 1e-3 bound is
-    an f16 statement; e4m3 carries 3 mantissa bits, so the fp8 bound asserted here is 1e-2 and the measured value
-    is printed (DESIGN.md quotes it).  Top-1 ids after the exact match are checked in test_fp8_ids_... below."""
+    """The fp8 path against the fp32 oracle: north_star's bound, 1 - cos < 1e-3, on r100_kat.npz AND on 64 further
+    crops, with the default selection (every eligible 14x14 conv + the last four 28x28 ones: 63 convs, 61 % of the
+    FLOPs on the fp8 matrix cores), centred activations and GPTQ-rounded weights.  The all-eligible setting (84 convs,
+    82 %) is measured and printed beside it (DESIGN.md quotes both)."""
     from facerecognition_infrenceengine_amd import weights
     from facerecognition_infrenceengine_amd.iresnet import IResNetHIP
-    net = IResNetHIP(weights.synth_iresnet_state("r100", seed=1234), "r100", "cuda:0")
+    from oracle import nets as onets
+    st = weights.synth_iresnet_state("r100", seed=1234)
+    net = IResNetHIP(st, "r100", "cuda:0")
     d = golden("r100_kat.npz")
-    x = nchw_to_nhwc8(torch.from_numpy(d["x"]))
-    g = torch.Generator().manual_seed(11)
-    calib = nchw_to_nhwc8(torch.rand((16, 3, 112, 112), generator=g) * 2 - 1)
+    xs = _structured_crops(64, 31)
+    ref = np.concatenate([d["embedding"], onets.iresnet_forward(st, xs, weights.IRESNET_LAYERS["r100"]).numpy()])
+    x = nchw_to_nhwc8(torch.cat([torch.from_numpy(d["x"]), xs]))
+    calib = nchw_to_nhwc8(_structured_crops(64, 32))
     e16, _ = net.forward(x)
-    n = net.enable_fp8(calib)
-    assert n == 2 * 12 + 1 + 2 * 29 + 1                       # stage 2: 12 blocks, stage 3: 29 blocks, + 2 stage-entry conv1s
-    e8, n8 = net.forward(x)
-    ref = d["embedding"]
     cos = lambda a, b: (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))   # noqa: E731
-    c8, c16 = cos(e8.cpu().numpy(), ref), cos(e16.cpu().numpy(), ref)
-    print(f"\\nfp8 r100: 1-cos vs fp32 oracle max {float((1 - c8).max()):.3e} (f16 path {float((1 - c16).max()):.3e})")
-    assert (1 - c8).max() < 1e-2, c8
+    c16 = cos(e16.cpu().numpy(), ref)
+    n = net.enable_fp8(calib, select="all")
+    assert n == 2 * 12 + 1 + 2 * 29 + 1                       # stage 2: 12 blocks, stage 3: 29 blocks, + 2 stage-entry conv1s
+    c_all = cos(net.forward(x)[0].cpu().numpy(), ref)
+    n = net.enable_fp8(calib)                                 # the default: "accurate"
+    assert n == 2 * 29 + 1 + 4
+    e8, n8 = net.forward(x)
+    c8 = cos(e8.cpu().numpy(), ref)
+    print(f"\nfp8 r100, 66 faces: 1-cos vs fp32 oracle max {float((1 - c8).max()):.3e} mean {float((1 - c8).mean()):.3e} "
+          f"(63 convs); all 84 eligible convs: max {float((1 - c_all).max()):.3e}; f16 path {float((1 - c16).max()):.3e}")
+    assert (1 - c8).max() < 1e-3, 1 - c8
+    assert (1 - c_all).max() < 2.5e-3
     np.testing.assert_allclose(np.linalg.norm(n8.cpu().numpy(), axis=1), 1.0, atol=1e-6)
     assert not torch.isnan(e8).any()
 
@@ -332,3 +411,58 @@ def test_fp8_ids_equal_oracle_ids_after_match():
         oi, _ = omatch.match_rows_fast(ref / np.linalg.norm(ref, axis=1, keepdims=True), G)
         assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(oi, 5000 + np.arange(64))
         assert float(score.min()) > 0.9
+
+
+def test_fp8_embeddings_near_threshold_and_near_tie_ids():
+    """fp8 EMBEDDINGS as queries against gallery rows placed around the decision boundaries: for every face a row at
+    0.4 - 1e-3 / 0.4 + 1e-3 (alternating), for some a pair of near-tie rows 1e-5 apart above it, for some an exact
+    duplicate pair (first row wins).  Ids and live decisions from the HIP match (exact f32 scan, and the fp8 coarse
+    scan + exact re-rank) must equal the literal reference loop's (oracle/match.py, infrenceServer.py:535-552) on the
+    same queries."""
+    from facerecognition_infrenceengine_amd import weights
+    from facerecognition_infrenceengine_amd.gallery import GalleryMatcher
+    from facerecognition_infrenceengine_amd.iresnet import IResNetHIP
+    from oracle import match as omatch
+    st = weights.synth_iresnet_state("r50", seed=5)
+    net = IResNetHIP(st, "r50", "cuda:0")
+    x = _structured_crops(48, 41)
+    assert net.enable_fp8(nchw_to_nhwc8(_structured_crops(32, 42))) > 0
+    _, n8 = net.forward(nchw_to_nhwc8(x))
+    Q = n8.cpu().numpy()
+    rng = np.random.default_rng(8)
+    rows = [r for r in rng.standard_normal((3000, 512)).astype(np.float32)]
+
+    def at(q, a):
+        """unit row with q . row = a (up to f32 rounding)"""
+        u = rng.standard_normal(512)
+        u -= (u @ q) * q
+        u /= np.linalg.norm(u)
+        return (a * q + np.sqrt(1 - a * a) * u).astype(np.float32)
+
+    for i, q in enumerate(Q.astype(np.float64)):
+        q = q / np.linalg.norm(q)
+        rows.append(at(q, 0.4 - 1e-3 if i % 2 == 0 else 0.4 + 1e-3))
+        if i % 3 == 0:
+            rows += [at(q, 0.6), at(q, 0.6 + 1e-5)]
+        if i % 5 == 0:
+            dup = at(q, 0.7)
+            rows += [dup, dup.copy()]
+    G = np.stack(rows)
+    G /= np.linalg.norm(G, axis=1, keepdims=True)
+    # faces of this synthetic net resemble each other: a face's "own" rows are not necessarily its best rows - the
+    # oracle decides, not the construction
+    gal = {str(i): G[i] for i in range(len(G))}
+    want_ids, want_dec = [], []
+    for q in Q:
+        qn = omatch.renormalise(q)
+        bid, bs = omatch.linear_scan(qn, gal)
+        want_ids.append(int(bid))
+        want_dec.append(omatch.decide_live(bid, bs)[0] is not None)
+    for scan in ("f32", "f8"):
+        m = GalleryMatcher("cuda:0", scan=scan)
+        m.set_rows(range(len(G)), G, normalise=False)
+        idx, score = m.match_device(n8)
+        dec = m.decide_device(idx, score, 0.4).cpu().numpy()
+        assert np.array_equal(idx.cpu().numpy(), np.array(want_ids)), scan
+        assert np.array_equal(dec == 1, np.array(want_dec)), scan
+    assert 0 < sum(want_dec) and len(set(want_ids)) > 8

@@ -104,6 +104,28 @@ def test_coarse_scan_with_f32_rerank_matches_f32_oracle(N, F, scan):
         assert int(idx[0]) == N // 2                                                    # duplicate rows: lowest row
 
 
+def test_fp8_scan_saturates_instead_of_nan_on_non_unit_rows():
+    """fp8 rows are e4m3(256 g): an element beyond 1.75 leaves the e4m3 range, where the bare conversion gives NaN and
+    a NaN coarse score fails every '>' - the row would never reach the exact re-rank even when it is the true best
+    match.  The packing saturates at +-448 instead: a non-unit gallery row (set_rows(normalise=False)) and a
+    non-unit query (renormalise=False) still come back with the f32 oracle's ids."""
+    from facerecognition_infrenceengine_amd.gallery import GalleryMatcher
+    rng = np.random.default_rng(31)
+    N = 3000
+    G = rng.standard_normal((N, 512)).astype(np.float32); G /= np.linalg.norm(G, axis=1, keepdims=True)
+    Q = rng.standard_normal((6, 512)).astype(np.float32); Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    G[1234] = 3.0 * Q[0]                        # not unit: the true best row of query 0, elements up to ~0.5 ... fine,
+    G[1234, 7] = 2.5                            # ... and one element past 1.75: 640 > 448 in the fp8 copy
+    Q[1] = 4.0 * G[77]; Q[1, 3] = 2.2           # a non-unit query with an out-of-range element
+    m = GalleryMatcher("cuda:0", scan="f8")
+    m.set_rows(list(range(N)), G, normalise=False)
+    idx, score = m.match_device(torch.from_numpy(Q).cuda(), renormalise=False)
+    oi, os_ = omatch.match_rows_fast(Q, G)
+    assert np.array_equal(idx.cpu().numpy(), oi) and int(oi[0]) == 1234
+    np.testing.assert_allclose(score.cpu().numpy(), os_, rtol=2e-6, atol=3e-6)
+    assert not torch.isnan(score).any()
+
+
 @pytest.mark.parametrize("scan,N", [("f16", 1_000_000), ("f8", 1_250_000)])
 def test_coarse_scan_full_size(scan, N):
     """C4's whole 1 M-row gallery (f16) and one of C5's 10 M / 8 = 1.25 M-row fp8 shards, 2048 gathered queries

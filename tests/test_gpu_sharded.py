@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 def _simulate(G, Qs, q_max, scan):
     """Every 'rank' r holds shard r and the queries Qs[r]; returns per-rank (idx, score) numpy."""
-    from facerecognition_infrenceengine_amd.distributed import HipOps, pack_candidates, reduce_packed, shard_rows
+    from facerecognition_infrenceengine_amd.distributed import (HipOps, gathered_counts, pack_candidates, pack_queries,
+                                                                reduce_packed, shard_rows)
     from facerecognition_infrenceengine_amd.gallery import GalleryMatcher
     R, N = len(Qs), len(G)
     ops = []
@@ -23,19 +24,23 @@ def _simulate(G, Qs, q_max, scan):
         m = GalleryMatcher("cuda:0", scan=scan)
         m.set_rows(range(lo, hi), G[lo:hi], normalise=False)
         ops.append(HipOps(m, lo))
-    # step 0/1: renormalise own rows, pad to q_max, "all-gather"
-    sends, counts = [], []
+    # step 0/1: renormalise own rows, pack (rows + zero padding + count row: fr_exchange_pack_queries), "all-gather"
+    seg = q_max + 1
+    sends = []
     for r in range(R):
         Qn = ops[r].renormalise(torch.from_numpy(Qs[r]).cuda())
-        pad = torch.zeros((q_max, 512), dtype=torch.float32, device="cuda")
-        pad[:len(Qs[r])] = Qn
-        sends.append(pad); counts.append(len(Qs[r]))
-    flat = torch.cat(sends)
-    cnt = torch.tensor(counts, dtype=torch.int32, device="cuda")
-    # step 2: every rank scans its shard for all gathered slots; step 3: pack, "all-gather", reduce own slots
+        send = ops[r].pack_queries(Qn, q_max)
+        assert torch.equal(send, pack_queries(Qn, q_max))                # HIP exchange glue == torch forms, bit for bit
+        sends.append(send)
+    allq = torch.cat(sends)
+    cnt = ops[0].gathered_counts(allq, R, q_max)
+    assert torch.equal(cnt, gathered_counts(allq, R, q_max)) and cnt.tolist() == [len(q) for q in Qs]
+    # step 2: every rank scans its shard for all gathered slots IN PLACE (a segment = q_max slots + the count row, which
+    # is padding); step 3: pack, "all-gather", reduce own slots
     packs = []
     for r in range(R):
-        idx, score = ops[r].scan(flat, counts=cnt, seg_len=q_max)
+        idx, score = ops[r].scan(allq, counts=cnt, seg_len=seg)
+        assert int(idx.view(R, seg)[:, q_max].max()) == -1               # the count row is never a query
         p = ops[r].pack(idx, score)
         assert torch.equal(p, pack_candidates(idx, score))               # HIP pack == torch pack, bit for bit
         packs.append(p)
@@ -43,8 +48,8 @@ def _simulate(G, Qs, q_max, scan):
     out = []
     for r in range(R):
         F = len(Qs[r])
-        bi, bs = ops[r].reduce(allp, R, R * q_max, r * q_max, F)
-        ti, ts = reduce_packed(allp, R, R * q_max, r * q_max, F)         # HIP reduce == torch reduce
+        bi, bs = ops[r].reduce(allp, R, R * seg, r * seg, F)
+        ti, ts = reduce_packed(allp, R, R * seg, r * seg, F)             # HIP reduce == torch reduce
         assert torch.equal(bi, ti) and torch.equal(bs, ts)
         out.append((bi.cpu().numpy(), bs.cpu().numpy()))
     return out

@@ -201,6 +201,59 @@ def test_camera_manager_batches_sources_and_keeps_reference_queue_semantics():
     assert all(getattr(c, "released", False) for c in caps.values())
 
 
+def test_camera_manager_backs_off_on_failed_reads_and_drains_results_by_default():
+    """A camera whose read() fails must not spin (capture threads share the interpreter with the batching loop): the
+    reads back off, the capture is re-opened after ``reopen_after`` failures and the source is given up after
+    ``dead_after``; without a display the default consumer keeps the latest frame per source, so the result queue
+    (maxsize 10) never fills and nothing is dropped; start without a capture_factory raises in the caller."""
+    import time
+    import pytest
+    from facerecognition_infrenceengine_amd.camera import CameraManager
+
+    class FlakyCap:
+        opened = 0
+
+        def __init__(self, source):
+            FlakyCap.opened += 1
+            self.source, self.reads, self.generation = source, 0, FlakyCap.opened
+
+        def read(self):
+            self.reads += 1
+            if self.source == "dead" or (self.source == "flaky" and self.generation == 1):
+                return False, None                              # a dropped stream: fails immediately, every time
+            return True, np.full((4, 6, 3), 5, np.uint8)
+
+        def release(self):
+            pass
+
+    class Proc:
+        def recognize_batch(self, frames, company_id):
+            time.sleep(0.001)
+            return [[] for _ in frames]
+
+        def annotate(self, frame, res):
+            return frame
+
+    with pytest.raises(RuntimeError):
+        CameraManager(None, processor=Proc()).start_cameras([0], "acme")
+    caps = []
+    cm = CameraManager(None, processor=Proc(), capture_factory=lambda s: caps.append(FlakyCap(s)) or caps[-1],
+                       reopen_after=3, dead_after=8)
+    cm.start_cameras(["flaky", "dead", "good"], "acme")
+    deadline = time.time() + 10
+    while time.time() < deadline and not (cm.stats["dead_sources"] and cm.latest_frame("flaky") is not None
+                                          and cm.stats["frames"] > 30):
+        time.sleep(0.01)
+    cm.stop_cameras()
+    assert cm.stats["dead_sources"] == ["dead"]
+    assert cm.latest_frame("flaky") is not None and cm.latest_frame("good") is not None and cm.latest_frame("dead") is None
+    first_flaky = next(c for c in caps if c.source == "flaky")
+    assert first_flaky.reads == 3                               # re-opened after 3 failures, not spun on
+    dead_reads = sum(c.reads for c in caps if c.source == "dead")
+    assert dead_reads == 8                                      # 8 backed-off reads in total, then given up
+    assert cm.stats["frames"] > 30 and cm.stats["dropped_results"] == 0
+
+
 def test_decode_image_is_the_imdecode_of_the_enrolment_path():
     """ingest.decode_image: encoded bytes -> BGR uint8 (trainingServer.py:219-221).  PNG round trip is lossless and
     must be exact incl. the channel order; JPEG decodes to within the codec's error; garbage gives None."""

@@ -47,3 +47,44 @@ def test_rejects_a_graph_that_is_not_an_iresnet(tmp_path):
     path.write_bytes(ow._vi(1, 7) + ow._ld(7, graph))
     with pytest.raises(ValueError, match="expected one Conv"):
         onnx_import.iresnet_state_from_onnx(str(path))
+
+
+def test_tensor_decoder_accepts_default_data_location_and_int32_payloads():
+    """TensorProto field 14 (data_location) = 0 is DEFAULT and legal when written explicitly; only 1 (EXTERNAL) is
+    unsupported.  Field 5 (int32_data) carries int32 payloads and float16 payloads as uint16 bit patterns."""
+    from tests.helpers import onnx_write as ow
+    a = np.arange(6, dtype=np.float32).reshape(2, 3) - 2.5
+    base = b"".join(ow._vi(1, d) for d in a.shape) + ow._ld(8, b"t")
+    name, got = onnx_import._tensor(base + ow._vi(2, 1) + ow._ld(9, a.tobytes()) + ow._vi(14, 0))
+    assert name == "t" and np.array_equal(got, a)
+    with pytest.raises(ValueError, match="external"):
+        onnx_import._tensor(base + ow._vi(2, 1) + ow._vi(14, 1))
+    h = a.astype(np.float16)
+    packed = b"".join(ow._varint(int(v)) for v in h.view(np.uint16).ravel())
+    _, got16 = onnx_import._tensor(base + ow._vi(2, 10) + ow._ld(5, packed))
+    assert got16.dtype == np.float16 and np.array_equal(got16, h)
+    ints = np.array([[3, -1, 0], [7, -70000, 2]], dtype=np.int32)
+    packed = b"".join(ow._varint(int(v)) for v in ints.ravel())
+    _, goti = onnx_import._tensor(base + ow._vi(2, 6) + ow._ld(5, packed))
+    assert goti.dtype == np.int32 and np.array_equal(goti, ints)
+
+
+def test_pack_with_onnx_files_but_no_readable_recognition_net_raises(tmp_path):
+    """A model directory that HOLDS .onnx files none of which maps onto an ArcFace IResNet must not fall back to
+    synthetic recognition weights silently (it would recognise nobody); unreadable files of any kind (truncated
+    protobuf: struct.error / IndexError / TypeError, not only ValueError) are skipped with their reason."""
+    from facerecognition_infrenceengine_amd import _lib
+    from facerecognition_infrenceengine_amd.face_analysis import FaceAnalysis
+    d = tmp_path / "models" / "pack"
+    d.mkdir(parents=True)
+    (d / "det_10g.onnx").write_bytes(b"\x3a\x05\x0a\x03abc")            # a graph with one garbage node
+    (d / "genderage.onnx").write_bytes(b"\x08")                        # truncated varint field
+    app = FaceAnalysis(name="pack", root=str(tmp_path))
+    with pytest.raises(_lib.FrError, match="none of its .onnx files"):
+        app._load_states()
+    # with a readable recognition network beside them the others are skipped and the pack loads
+    st = weights.synth_iresnet_state("r18", seed=3)
+    write_iresnet_onnx(d / "w600k_r18.onnx", {k: v.numpy() for k, v in st.items()}, "r18", fold_bn=False)
+    with pytest.warns(UserWarning, match="MTCNN detector"):
+        rec, det = app._load_states()
+    assert app.arch == "r18" and np.array_equal(rec["conv1.weight"].numpy(), st["conv1.weight"].numpy())
