@@ -67,6 +67,9 @@ SIGNATURES = {
     "fr_quantize_f16_f8": (_I, [_P, _P, _L, _F, _P]),
     "fr_quantize_f16_f8_centred": (_I, [_P, _P, _L, _I, _P, _F, _P]),
     "fr_gptq_round_e4m3": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "fr_conv_stage14_weight_bytes": (_Z, [_I]),
+    "fr_conv_stage14_pack": (_I, [_P, _P, _P]),
+    "fr_conv_stage14_f16": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "fr_conv_splitk_epilogue": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
     "fr_fc_reduce_l2norm": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
     "fr_warp_affine_5pt": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P]),

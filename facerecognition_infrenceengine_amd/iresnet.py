@@ -33,6 +33,9 @@ SMALL_BATCH = 48      # measured crossover: 32 faces 2.7 vs 3.3 ms, 64 faces 4.6
 LOW_BATCH = 8
 # single-frame plans (4 x 12.8 MB of activations + ~40 MB of split-K scratch per HIP stream) are kept for this many streams
 MAX_PLAN_STREAMS = 8
+# from this many faces up the stride-1 blocks of the 14x14 stage run as ONE launch with the image resident in LDS
+# (fr_conv_stage14_f16: one workgroup per image, one image per CU); below, the per-layer path fills the CUs better
+STAGE14_MIN_BATCH = 128
 
 
 def _bn_fold(st, prefix, n, conv=None):
@@ -209,6 +212,7 @@ class IResNetHIP:
             if ds is not None:
                 sc = _Conv(_pack_w(ds["w"]), ds["bias"], None, ds["cin"], ds["cout"], 1, ds["stride"], 0, 0, dev)
             self.blocks.append((c1, c2, sc))
+        self._pack_stage14()
         self.fc_w = f["fc_w"].to(torch.float16).contiguous().to(dev)
         self.fc_bias = f["fc_bias"].to(torch.float32).contiguous().to(dev)
         self.flops_per_face = self._count_flops()
@@ -218,7 +222,49 @@ class IResNetHIP:
         self._plan_limit_logged = False
         self.profile = None          # bench.py: list collecting (kernel variant, flops, ev0, ev1) per conv launch
         self.fp8 = False             # enable_fp8(): eligible body convs run on the fp8 matrix cores
+        self.use_stage14 = True      # False: the 14x14 stage runs layer by layer whatever the batch (A/B, tests)
         self._calib = None
+
+    # ---- the 14x14 stage as one launch (fr_conv_stage14_f16)
+    def _pack_stage14(self):
+        """The longest run of consecutive stride-1 256 -> 256 blocks (r100: blocks 17..45, the 29 blocks behind stage
+        3's entry block): their weights as ONE pre-swizzled stream in kernel order + [10][256] f32 parameters per conv
+        (nine border-class biases - a plain bias nine times - and the PReLU slope, 1.0 = none)."""
+        self.stage14 = None
+        run, best = [], []
+        for i, (c1, c2, sc) in enumerate(self.blocks):
+            ok = sc is None and c1.cin == 256 and c1.cout == 256 and c2.stride == 1 and c2.cout == 256
+            run = run + [i] if ok else []
+            if len(run) > len(best):
+                best = run
+        if len(best) < 2:
+            return
+        nconv = 2 * len(best)
+        per = self.lib.fr_conv_stage14_weight_bytes(1) // 2
+        stream = torch.empty(nconv * per, dtype=torch.float16, device=self.device)
+        prm = torch.empty((nconv, 10, 256), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            for k, i in enumerate(best):
+                c1, c2, _ = self.blocks[i]
+                for j, c in enumerate((c1, c2)):
+                    self.lib.fr_conv_stage14_pack(_lib.ptr(c.w), _lib.ptr(stream[(2 * k + j) * per:]), _lib.stream_ptr())
+                    prm[2 * k + j, :9] = c.bias.reshape(9, 256) if c.bias_mode == 1 else c.bias[None, :]
+                    prm[2 * k + j, 9] = c.slope if c.slope is not None else 1.0
+            torch.cuda.synchronize(self.device)
+        self.stage14 = {"first": best[0], "n": len(best), "w": stream, "prm": prm.contiguous()}
+
+    def _run_stage14(self, h, B):
+        st = self.stage14
+        y = torch.empty_like(h)
+        if self.profile is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.lib.fr_conv_stage14_f16(_lib.ptr(h), _lib.ptr(y), _lib.ptr(st["w"]), _lib.ptr(st["prm"]), B, st["n"], _lib.stream_ptr())
+            e1.record()
+            self.profile.append(("conv_stage14_kernel", 2.0 * B * 196 * 256 * 2304 * 2 * st["n"], e0, e1))
+        else:
+            self.lib.fr_conv_stage14_f16(_lib.ptr(h), _lib.ptr(y), _lib.ptr(st["w"]), _lib.ptr(st["prm"]), B, st["n"], _lib.stream_ptr())
+        return y
 
     # ---- fp8 path (BASELINE config C5)
     def fp8_candidates(self):
@@ -533,7 +579,13 @@ class IResNetHIP:
         li = 0
         h8 = None                                  # fp8 copy of h, scaled for the conv that will read it (or None)
         nb = len(self.blocks)
+        use_stage = (self.stage14 is not None and self.use_stage14 and B >= STAGE14_MIN_BATCH and taps is None
+                     and self._calib is None and not self.fp8)
         for bi_, (c1, c2, sc) in enumerate(self.blocks):
+            if use_stage and self.stage14["first"] <= bi_ < self.stage14["first"] + self.stage14["n"]:
+                if bi_ == self.stage14["first"]:
+                    h = self._run_stage14(h, B)        # all n blocks; the loop skips the rest of the run
+                continue
             self._calib_observe(c1, h, H)              # enable_fp8(): statistics of the tensors the candidates read
             f1 = self.fp8 and c1.oscale is not None
             f2 = self.fp8 and c2.oscale is not None

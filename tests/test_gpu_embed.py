@@ -204,6 +204,83 @@ def test_r50_variant_vs_oracle():
     assert abs(net.flops_per_face / 1e9 - 12.6) < 0.2          # 12.62 GFLOP / face
 
 
+# ---------------------------------------------------------------- the 14x14 stage as one launch (conv_stage14.hip)
+@pytest.mark.parametrize("B,nblocks", [(1, 1), (3, 2), (5, 3)])
+def test_stage14_kernel_vs_torch(lib, B, nblocks):
+    """fr_conv_stage14_f16 (image resident in LDS, weights streamed, in-place convs) against plain torch fp32 on the
+    same f16-rounded operands, with the kernel's roundings (one f16 rounding per conv output): conv3x3 + 9-class
+    border bias + PReLU, conv3x3 + bias + residual, block after block.  Odd batch, 1 .. 3 blocks."""
+    from facerecognition_infrenceengine_amd import _lib
+    g = torch.Generator().manual_seed(100 + B)
+    x = torch.randn((B, 14, 14, 256), generator=g).to(torch.float16)
+    per = lib.fr_conv_stage14_weight_bytes(1) // 2
+    stream = torch.empty(2 * nblocks * per, dtype=torch.float16, device="cuda")
+    prm = torch.empty((2 * nblocks, 10, 256), dtype=torch.float32)
+    ws = []
+    rc = torch.ones(14, dtype=torch.long); rc[0] = 0; rc[-1] = 2
+    h = x.float().permute(0, 3, 1, 2)
+    for k in range(nblocks):
+        w1 = (torch.randn((256, 3, 3, 256), generator=g) * (2.0 / 2304) ** 0.5).to(torch.float16)
+        w2 = (torch.randn((256, 3, 3, 256), generator=g) * (0.3 / 2304) ** 0.5).to(torch.float16)
+        b9 = torch.randn((3, 3, 256), generator=g) * 0.3
+        sl = torch.rand(256, generator=g) * 0.5
+        b2 = torch.randn(256, generator=g) * 0.1
+        prm[2 * k, :9] = b9.reshape(9, 256); prm[2 * k, 9] = sl
+        prm[2 * k + 1, :9] = b2[None, :]; prm[2 * k + 1, 9] = 1.0
+        for j, w in enumerate((w1, w2)):
+            wd = w.reshape(256, 2304).contiguous().cuda()
+            ws.append(wd)
+            lib.fr_conv_stage14_pack(_lib.ptr(wd), _lib.ptr(stream[(2 * k + j) * per:]), _lib.stream_ptr())
+        mid = F.conv2d(h, w1.float().permute(0, 3, 1, 2), None, 1, 1) + b9[rc][:, rc].permute(2, 0, 1)[None]
+        mid = torch.where(mid > 0, mid, mid * sl[None, :, None, None]).to(torch.float16).float()
+        h = (F.conv2d(mid, w2.float().permute(0, 3, 1, 2), None, 1, 1) + b2[None, :, None, None] + h).to(torch.float16).float()
+    xd, pd = x.cuda(), prm.cuda()
+    y = torch.empty_like(xd)
+    lib.fr_conv_stage14_f16(_lib.ptr(xd), _lib.ptr(y), _lib.ptr(stream), _lib.ptr(pd), B, nblocks, _lib.stream_ptr())
+    torch.cuda.synchronize()
+    ref = h.permute(0, 2, 3, 1)
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err <= 3e-3 * ref.abs().max().item(), (err, ref.abs().max().item())
+    # the same through the per-layer kernels: differences are f32 summation order + f16 rounding ties only
+    hh = xd
+    for k in range(nblocks):
+        m_ = torch.empty_like(xd); o_ = torch.empty_like(xd)
+        b9d, sld, b2d = pd[2 * k, :9].reshape(-1).contiguous(), pd[2 * k, 9].contiguous(), pd[2 * k + 1, 0].contiguous()
+        a = _lib.ConvArgs(_lib.ptr(hh), _lib.ptr(ws[2 * k]), _lib.ptr(m_), _lib.ptr(b9d), _lib.ptr(sld), None, None,
+                          B, 14, 14, 256, 256, 3, 3, 1, 1, 14, 14, 1, 1)
+        lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
+        a = _lib.ConvArgs(_lib.ptr(m_), _lib.ptr(ws[2 * k + 1]), _lib.ptr(o_), _lib.ptr(b2d), None, _lib.ptr(hh), None,
+                          B, 14, 14, 256, 256, 3, 3, 1, 1, 14, 14, 0, 1)
+        lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
+        hh = o_
+    torch.cuda.synchronize()
+    d = (y.float() - hh.float()).abs()
+    assert d.max().item() <= 2e-3 * ref.abs().max().item() and (d > 0).float().mean().item() < 0.02
+
+
+def test_stage14_path_on_r100_vs_golden_and_layer_path(r100, golden):
+    """From 128 faces up the 29 stride-1 blocks of stage 3 run as ONE launch.  The two golden faces inside such a batch
+    must meet north_star's bound against the fp32 oracle, and the whole batch must agree with the layer-by-layer path
+    to f16 rounding noise (another f32 summation order: tap-major instead of chunk-major)."""
+    d = golden("r100_kat.npz")
+    g = torch.Generator().manual_seed(6)
+    x = torch.cat([torch.from_numpy(d["x"]), torch.rand((127, 3, 112, 112), generator=g) * 2 - 1])     # odd batch
+    xa = nchw_to_nhwc8(x)
+    assert r100.stage14 is not None and r100.stage14["n"] == 29
+    e_stage, n_stage = r100.forward(xa)
+    r100.use_stage14 = False
+    try:
+        e_layer, _ = r100.forward(xa)
+    finally:
+        r100.use_stage14 = True
+    cos = torch.nn.functional.cosine_similarity(e_stage, e_layer).min().item()
+    assert 1 - cos < 1e-5, cos
+    got, ref = e_stage[:2].cpu().numpy(), d["embedding"]
+    c = (got * ref).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(ref, axis=1))
+    assert (1 - c).max() < 1e-3, c
+    np.testing.assert_allclose(np.linalg.norm(n_stage.cpu().numpy(), axis=1), 1.0, atol=1e-6)
+
+
 # ---------------------------------------------------------------- fp8 body convs (BASELINE config C5)
 def _f8(t):
     """Round a float tensor to OCP e4m3 and back (values the kernel sees exactly)."""
