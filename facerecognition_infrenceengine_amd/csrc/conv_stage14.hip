@@ -15,16 +15,17 @@
 //        ring    3 slots x [256 couts][32 channels] f16 (16 KB): one K step = one tap x 32 channels = ONE MFMA per
 //                tile pair; 64-B rows, chunk' = chunk ^ (((row >> 3) & 1) << 1) (conflict-free)
 //   waves 8 = 4 cout groups (wn = plane of the output) x 2 pixel groups (6 tiles of 16 pixels each); the 13th pixel
-//         tile (pixels 192..195) is shared by cout: 2 cout tiles per wave -> 26 accumulator tiles per wave, every wave
+//         tile (pixels 192..195) is shared by cout: 2 cout tiles per wave (with the wave's own weight fragments) -> 26
+//         accumulator tiles per wave, every wave; 256 VGPRs, no spill inside the K loop
 //   step  s: wait own W(s+1) pieces (W(s+2) stays in flight) -> barrier -> 26 MFMAs on the fragments read during step
 //         s-1, with the 11 fragment reads of step s+1 between them and the DMA of W(s+3) into step s's own slot before
-//         (one wave of a SIMD pair) or behind them (the other)
-//   conv  a block's second conv starts from accumulators that hold the block's input (the residual, read back from HBM
-//         with L1-bypassing loads under the first conv's epilogue); end: barrier -> bias (9 border classes) -> PReLU (slope 1 = none) -> f16
-//         into the image in place -> barrier; after a block's second conv the image is also copied to HBM (the next
-//         block's residual and, at the end, the result): coalesced 16-B stores.
+//         them (one wave of a SIMD pair) or in their middle (the other)
+//   conv  end: barrier -> bias (9 border classes) -> PReLU -> f16 into the image in place -> barrier.  A block's second
+//         conv starts from accumulators that hold the block's input (the residual): the first conv's epilogue reads
+//         each old image element just before it overwrites it.  The residual stream never leaves the CU: HBM sees the
+//         run's input and, after the last conv, its result (coalesced 16-B stores).
 //
-// Weight stream (host: iresnet.py pack_stage_weights): per conv 72 slots, slot = step q = tap * 8 + g (g = 32-channel
+// Weight stream (host: iresnet.py _pack_stage14 -> fr_conv_stage14_pack): per conv 72 slots, slot = step q = tap * 8 + g (g = 32-channel
 // group), each 16 KB in LDS image order.  Parameters per conv: f32 [10][256] = 9 border-class biases + PReLU slope.
 #include "common.h"
 #include <type_traits>
@@ -106,11 +107,11 @@ __global__ __launch_bounds__(512, 2) void conv_stage14_kernel(StageP p) {
     issue_w(2);
     // a conv's parameters (10 KB) -> LDS, by LDS-DMA too: pieces 0..7 by the 8 waves, 8..9 by waves 0 and 1
     __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)p.prm, 0, (unsigned)p.nconv * S14_PRM, 0x00020000);
-    auto issue_prm = [&](int conv) {
+    auto issue_prm = [&](int conv, int ln) {
         char* dst = lds + S14_IMG + 3 * S14_SLOT;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (lds_ptr_t)(dst + wave * 1024), 16, (unsigned)(wave * 1024 + lane * 16), conv * S14_PRM, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (lds_ptr_t)(dst + wave * 1024), 16, (unsigned)(wave * 1024 + ln * 16), conv * S14_PRM, 0, 0);
         if (wave < 2)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (lds_ptr_t)(dst + (8 + wave) * 1024), 16, (unsigned)((8 + wave) * 1024 + lane * 16), conv * S14_PRM, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (lds_ptr_t)(dst + (8 + wave) * 1024), 16, (unsigned)((8 + wave) * 1024 + ln * 16), conv * S14_PRM, 0, 0);
     };
 
     // ---- image: HBM [196][512 B] -> 4 planes x 200 rows x 128 B (rows >= 196 and the tail: out of range -> zeros)
@@ -135,12 +136,17 @@ __global__ __launch_bounds__(512, 2) void conv_stage14_kernel(StageP p) {
     int4v a0[4], a1[4], b[6], bx;
     int boff[7];        // per tap: byte offset of the lane's tap pixel row + chunk bits, for even g; odd g: ^ 64
 
+    // per-conv copies of the lane constants, re-derived from the lane id at every conv start behind an opaque asm:
+    // hipcc otherwise hoists the ~100 addresses they determine (the first tap's pixel offsets, residual loads, epilogue
+    // stores) out of the conv loop, keeps them in scratch and reloads them one by one, each reload behind a
+    // vmcnt(0) that also waits for every weight DMA in flight (measured: 6 000 cycles per conv start)
+    int px0e = px0, fre = fr, fqe = fq;
     auto set_tap_one = [&](int j, int dy, int dx) {                  // dy, dx in -1..1
-        const int px = j < 6 ? px0 + 16 * j : 192 + fr;
+        const int px = j < 6 ? px0e + 16 * j : 192 + fre;
         const int oy = px / 14, ox = px - oy * 14;
         const bool ok = px < S14_PX && (unsigned)(oy + dy) < 14u && (unsigned)(ox + dx) < 14u;
         const int pxn = ok ? px + dy * 14 + dx : S14_PX;             // the zero row
-        boff[j] = pxn * 128 + ((fq ^ (pxn & 7)) << 4);
+        boff[j] = pxn * 128 + ((fqe ^ (pxn & 7)) << 4);
     };
     auto set_tap = [&](int dy, int dx) {
 #pragma unroll
@@ -185,9 +191,10 @@ __global__ __launch_bounds__(512, 2) void conv_stage14_kernel(StageP p) {
         // order, so `lgkmcnt(1)` at the next step's top proves every weight read (the slot about to be overwritten) done
         // while b[5]' is still in flight: the image does not change inside a conv, a pixel read may cross the barrier.
         // The weight DMA of step k + 3 (into this step's own slot): an LDS-DMA piece holds the issuing wave for 100+ cycles,
-        // so the two waves of a SIMD (w and w + 4) take opposite ends of the step - the first issues its two pieces
-        // before its MFMAs, while the partner has the matrix pipe to itself; the partner issues its pieces behind its
-        // last MFMA, while the first wave catches up.
+        // so the two waves of a SIMD (w and w + 4) take turns - the first issues its two pieces before its MFMAs, while
+        // the partner has the matrix pipe to itself; the partner issues its pieces behind its 18th MFMA (about when the
+        // first wave's pieces are out), while the first wave has the pipe (stamps: DMA in the middle of both streams
+        // 1 470 cycles per step, first / last 1 180, first / 18th: see DESIGN.md).
         if (wp == 0 && !(ABL & 4)) { issue_w(k % 3); S14_PIN(); }
         // the shared 13th pixel tile: this wave's cout tiles 2 wp, 2 wp + 1 of its own four - the same weight fragments
         if (wp == 0) { accx[0] = mm(ac[0], bx, accx[0]); accx[1] = mm(ac[1], bx, accx[1]); }
@@ -216,8 +223,8 @@ __global__ __launch_bounds__(512, 2) void conv_stage14_kernel(StageP p) {
                 b[5] = rd_b(ng, 5);
             }
             S14_PIN();
+            if (j == 3 && wp == 1 && !(ABL & 4)) { issue_w(k % 3); S14_PIN(); }
         }
-        if (wp == 1 && !(ABL & 4)) { issue_w(k % 3); S14_PIN(); }
     };
 
 #pragma unroll
@@ -229,12 +236,10 @@ __global__ __launch_bounds__(512, 2) void conv_stage14_kernel(StageP p) {
     for (int conv = 0; conv < p.nconv; ++conv) {
         S14_STAMP(tC);
         if (STAMPS && conv) se += tC - tB;                           // the previous conv's epilogue
-        issue_prm(conv);                                             // read in this conv's epilogue, 72 steps from here
-        // laundered copies of the lane constants: hipcc otherwise hoists the ~100 addresses they determine (residual
-        // loads, epilogue stores) out of the conv loop and keeps them in scratch (measured: 120 spilled VGPRs, reloaded
-        // one by one right before each use)
-        int px0e = px0, fre = fr, fqe = fq;
-        asm volatile("" : "+v"(px0e), "+v"(fre), "+v"(fqe));
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        fre = lane_e & 15; fqe = lane_e >> 4; px0e = wp * 96 + fre;
+        issue_prm(conv, lane_e);                                     // read in this conv's epilogue, 72 steps from here
         // prologue: fragments of the conv's first step (its slot, 0, landed before the previous conv's last barrier)
         set_tap(-1, -1);
 #pragma unroll
@@ -274,79 +279,67 @@ __global__ __launch_bounds__(512, 2) void conv_stage14_kernel(StageP p) {
         asm volatile("" : "+v"(px0e), "+v"(fre), "+v"(fqe));
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");             // the parameters: older than the 2 weight pieces in flight
         __builtin_amdgcn_s_barrier();                                // every wave has consumed its last fragments of the old image
+        S14_STAMP(t1);
+        if (STAMPS == 1) sw += t1 - tB;                              // level-1 stamps: epilogue segments in the per-step slots
         // First conv of a block: the NEXT conv's accumulators start as the block's input (the residual), so that its
-        // epilogue needs no second operand: as soon as a tile's accumulator has been written out it is re-filled with
-        // the residual of that tile, loaded RQ tiles ahead (a window of 2 RQ registers: all 26 tiles at once beside the
-        // 26 accumulator tiles do not fit the register file).  The block's input is x for the first block, else what
-        // this workgroup wrote to y one block ago: L1-BYPASSING loads (sc1) - a CU's vector L1 is never refreshed by
-        // stores.
-        constexpr int RQ = 8;
-        __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)(conv == 0 ? p.x : (const half_t*)p.y), 0, p.xbytes, 0x00020000);
-        const unsigned rb = (unsigned)n * (unsigned)(S14_PX * S14_C * 2);
+        // epilogue needs no second operand.  That input is the OLD image - still in LDS, and the element a lane is about
+        // to overwrite with its output is exactly the residual element it needs: read, then write.  The residual
+        // stream never leaves the CU; HBM sees the run's input and its last block's output only.
         // per pixel tile j (6 own + the shared one): LDS row offset, swizzle key, parameter row of the pixel's border class
-        // (in floats), residual offset; per cout tile: channel offsets.  px < 196 holds for the own tiles by construction.
+        // (in floats); per cout tile: channel offsets.  px < 196 holds for the own tiles by construction.
         int rowoff[7], key[7], clsoff[7];
-        unsigned resoff[7];
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             const int px = j < 6 ? px0e + 16 * j : 192 + fre;
             const int oy = (px * 4682) >> 16, ox = px - oy * 14;     // px / 14 for px < 256
             const int cls = (oy == 0 ? 0 : (oy >= 13 ? 2 : 1)) * 3 + (ox == 0 ? 0 : (ox == 13 ? 2 : 1));
             clsoff[j] = cls * S14_C;
-            rowoff[j] = wn * S14_PLANE + px * 128 + (fqe & 1) * 8;
-            key[j] = px & 7;
-            resoff[j] = (j < 6 || px < S14_PX) ? (unsigned)(px * S14_C) * 2 : 0x80000000u;
+            const int pxr = px < S14_PX ? px : S14_PX;               // dead lanes of the shared tile: the plane's zero row (never written)
+            rowoff[j] = wn * S14_PLANE + pxr * 128 + (fqe & 1) * 8;
+            key[j] = pxr & 7;
         }
         const int co_own = wn * 64 + fqe * 4, co_sh = wn * 64 + wp * 32 + fqe * 4;      // + 16 per cout tile
         const int ch_own = fqe >> 1, ch_sh = wp * 4 + (fqe >> 1);                       // 16-B chunk inside the plane row: + 2 per cout tile
-        auto load_res = [&](int t) {
-            const int j = t < 24 ? t >> 2 : 6, co = t < 24 ? co_own + (t & 3) * 16 : co_sh + (t - 24) * 16;
-            return __builtin_bit_cast(int2v, __builtin_amdgcn_raw_buffer_load_b64(rrs, resoff[j] + (unsigned)co * 2, rb, 16));
-        };
         // PRELU is a compile-time flag of two copies of the tile loop: a block's second conv has none (slope 1)
-        auto finish = [&](float4v v, int t, const float4v& sl, auto prelu_tag) {
-            const int j = t < 24 ? t >> 2 : 6, co = t < 24 ? co_own + (t & 3) * 16 : co_sh + (t - 24) * 16;
-            const int ch = t < 24 ? ch_own + (t & 3) * 2 : ch_sh + (t - 24) * 2;
-            v += *reinterpret_cast<const float4v*>(lprm + clsoff[j] + co);
-            if constexpr (decltype(prelu_tag)::value) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * sl[e];
-            }
-            const half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-            half4* dst = reinterpret_cast<half4*>(img + rowoff[j] + ((ch ^ key[j]) << 4));
-            if (t < 24) *dst = h;
-            else if (192 + fre < S14_PX) *dst = h;
-        };
         auto tiles = [&](auto prelu_tag) {
             constexpr bool FIRST = decltype(prelu_tag)::value;       // first conv of a block: PReLU, and the residual refill
             float4v sl[4], slx[2];                                   // slopes depend on the cout only: once per conv
-            int2v rq[RQ];
             if constexpr (FIRST) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sl[i] = *reinterpret_cast<const float4v*>(lprm + 9 * S14_C + co_own + i * 16);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) slx[t] = *reinterpret_cast<const float4v*>(lprm + 9 * S14_C + co_sh + t * 16);
-#pragma unroll
-                for (int t = 0; t < RQ; ++t) rq[t] = load_res(t);
             }
 #pragma unroll
             for (int t = 0; t < 26; ++t) {
                 float4v& a_ = t < 24 ? acc[t >> 2][t & 3] : accx[t - 24];
-                finish(a_, t, t < 24 ? sl[t & 3] : slx[t - 24], prelu_tag);
+                const int j = t < 24 ? t >> 2 : 6, co = t < 24 ? co_own + (t & 3) * 16 : co_sh + (t - 24) * 16;
+                const int ch = t < 24 ? ch_own + (t & 3) * 2 : ch_sh + (t - 24) * 2;
+                half4* dst = reinterpret_cast<half4*>(img + rowoff[j] + ((ch ^ key[j]) << 4));
+                float4v v = a_ + *reinterpret_cast<const float4v*>(lprm + clsoff[j] + co);
                 if constexpr (FIRST) {
-                    const half4 h = __builtin_bit_cast(half4, rq[t % RQ]);
-                    a_ = float4v{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
-                    if (t + RQ < 26) rq[t % RQ] = load_res(t + RQ);
+                    const half4 old = *dst;                          // the block's input at the element this lane overwrites (dead lanes: a zero row)
+                    const float4v s_ = t < 24 ? sl[t & 3] : slx[t - 24];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * s_[e];
+                    a_ = float4v{(float)old[0], (float)old[1], (float)old[2], (float)old[3]};
                 } else {
                     a_ = float4v{0.f, 0.f, 0.f, 0.f};
                 }
+                const half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                if (t < 24) *dst = h;
+                else if (192 + fre < S14_PX) *dst = h;
                 if ((t & 3) == 3) S14_PIN();
             }
         };
         if (second) tiles(std::false_type{}); else tiles(std::true_type{});
+        S14_STAMP(t2);
+        if (STAMPS == 1) sb += t2 - t1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                // the new image is complete
-        if (second) {                                                // block output -> HBM (next block's residual; the result)
+        S14_STAMP(t3);
+        if (STAMPS == 1) sm += t3 - t2;
+        if (conv == p.nconv - 1) {                                   // the run's result -> HBM
             for (int e = tid; e < S14_PX * 32; e += 512) {           // 16-B chunks: pixel x 32 chunks
                 const int px = e >> 5, c = e & 31;                   // c = plane * 8 + chunk
                 const int4v v = *reinterpret_cast<const int4v*>(img + (c >> 3) * S14_PLANE + px * 128 + (((c & 7) ^ (px & 7)) << 4));

@@ -174,10 +174,11 @@ int fr_quantize_f16_f8_centred(const void* x16, void* out8, int64_t n, int C, co
  * 58 convs, 57 % of the network's FLOPs) as ONE launch with the image resident in LDS: one workgroup per image, a
  * conv's output overwrites its input in place, only the weights stream (conv_stage14.hip).  Same math as the
  * per-layer calls: block = conv3x3(+9-class border bias, PReLU) -> conv3x3(+bias) + input, f32 accumulation, one
- * rounding to f16 per conv output.  x: f16 NHWC [B,14,14,256] (input of the first block), y: same shape (receives
- * every block's output in turn; the last one stays), x != y.  wstream: the convs' weights in kernel order (conv1,
- * conv2 of block 0, conv1 of block 1, ...), each re-ordered by fr_conv_stage14_pack from the [256][9*256] f16 layout of
- * fr_conv_nhwc_f16 into 72 x 16 KB slot images (fr_conv_stage14_weight_bytes(1) bytes per conv).  params: f32
+ * rounding to f16 per conv output.  x: f16 NHWC [B,14,14,256] (input of the first block), y: same shape (the last
+ * block's output; nothing else is written - the residual stream stays in LDS), x != y.  wstream: the convs' weights
+ * in kernel order (conv1, conv2 of block 0, conv1 of block 1, ...), each re-ordered by fr_conv_stage14_pack from the
+ * [256][9*256] f16 layout of fr_conv_nhwc_f16 into 72 x 16 KB slot images (fr_conv_stage14_weight_bytes(1) bytes per
+ * conv).  params: f32
  * [2*nblocks][10][256]: rows 0..8 the bias of border class (row class * 3 + column class) - a conv with a plain bias
  * repeats it nine times - row 9 the PReLU slope (1.0 = none). */
 size_t fr_conv_stage14_weight_bytes(int nconv);

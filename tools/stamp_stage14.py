@@ -47,6 +47,9 @@ for abl in ABLS:
           f"{(d[:, 5] / d[:, 6].clamp_min(1) * 100).mean():.0f} MHz; per conv {tot.mean().item() / nconv:.0f} cycles = "
           f"{(d[:, 6].mean().item() / 100) / nconv:.1f} us; K loop {d[:, 7].mean().item() / nconv:.0f} ({d[:, 7].mean().item() / steps:.0f} per step; MFMA-bound 832), "
           f"epilogue {d[:, 3].mean().item() / nconv:.0f}, prologue {d[:, 4].mean().item() / nconv:.0f}", flush=True)
+    if os.environ.get("FR_S14_STAMP_LEVEL", "2") == "1":
+        print(f"      epilogue segments per conv: wait+barrier {d[:, 0].mean().item() / nconv:.0f}, tiles {d[:, 1].mean().item() / nconv:.0f}, "
+              f"lgkm+barrier {d[:, 2].mean().item() / nconv:.0f}, rest (HBM copy of second convs) {(d[:, 3] - d[:, 0] - d[:, 1] - d[:, 2]).mean().item() / nconv:.0f}")
     if abl == 0 and os.environ.get("FR_S14_STAMP_LEVEL", "2") == "2":
         for k, nme in enumerate(names[:3]):
             print(f"   {nme:30s} {d[:, k].mean().item() / steps:9.1f} cycles per step")
