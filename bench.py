@@ -38,7 +38,7 @@ GALLERY_ROWS = 10_000
 FACES_PER_FRAME = 4                    # O-Net cap (C2 keeps F = 4 -> 256 faces/batch)
 MFMA_PEAK_TFLOPS = 2500.0              # dense f16/bf16 (MI355X_MICROARCH.md)
 MFMA_PEAK_TFLOPS_F8 = 5000.0           # dense fp8 (block-scaled MFMA with unit scales)
-PMC_FILE = "profiles/r02_pmc_traffic.json"
+PMC_FILE = "profiles/r03_pmc_traffic.json"
 
 
 def synth_frames(n, h, w, seed, device):

@@ -261,7 +261,7 @@ class IResNetHIP:
             e0.record()
             self.lib.fr_conv_stage14_f16(_lib.ptr(h), _lib.ptr(y), _lib.ptr(st["w"]), _lib.ptr(st["prm"]), B, st["n"], _lib.stream_ptr())
             e1.record()
-            self.profile.append(("conv_stage14_kernel", 2.0 * B * 196 * 256 * 2304 * 2 * st["n"], e0, e1))
+            self.profile.append(("conv_stage14_kernel<0, 0>", 2.0 * B * 196 * 256 * 2304 * 2 * st["n"], e0, e1))
         else:
             self.lib.fr_conv_stage14_f16(_lib.ptr(h), _lib.ptr(y), _lib.ptr(st["w"]), _lib.ptr(st["prm"]), B, st["n"], _lib.stream_ptr())
         return y

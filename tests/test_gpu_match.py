@@ -120,9 +120,10 @@ def test_fp8_scan_saturates_instead_of_nan_on_non_unit_rows():
     m = GalleryMatcher("cuda:0", scan="f8")
     m.set_rows(list(range(N)), G, normalise=False)
     idx, score = m.match_device(torch.from_numpy(Q).cuda(), renormalise=False)
-    oi, os_ = omatch.match_rows_fast(Q, G)
-    assert np.array_equal(idx.cpu().numpy(), oi) and int(oi[0]) == 1234
-    np.testing.assert_allclose(score.cpu().numpy(), os_, rtol=2e-6, atol=3e-6)
+    S = Q @ G.T                                 # renormalise=False: raw dots of the non-unit query
+    oi = S.argmax(axis=1)
+    assert np.array_equal(idx.cpu().numpy(), oi) and int(oi[0]) == 1234 and int(oi[1]) == 77
+    np.testing.assert_allclose(score.cpu().numpy(), S[np.arange(6), oi], rtol=2e-6, atol=3e-6)
     assert not torch.isnan(score).any()
 
 

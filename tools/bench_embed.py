@@ -7,7 +7,8 @@ from facerecognition_infrenceengine_amd.iresnet import IResNetHIP
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 net = IResNetHIP(weights.synth_iresnet_state("r100"), "r100", "cuda:0")
 x = (torch.rand((B, 112, 112, 8), device="cuda") * 2 - 1).half(); x[..., 3:] = 0
-for mode in ("f16", "fp8"):
+MODES = sys.argv[2].split(",") if len(sys.argv) > 2 else ["f16", "fp8"]
+for mode in MODES:
     if mode == "fp8":
         net.enable_fp8(x[:32].contiguous())
     for _ in range(3): net.forward(x)
