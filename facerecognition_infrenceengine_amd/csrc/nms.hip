@@ -1,8 +1,9 @@
 // Sort (descending score, ties by slot = stable) + greedy NMS, one workgroup per list.
 // MTCNN post-processing inside FaceAnalysis.get (/root/reference/infrenceServer.py:528); mirrors
 // oracle/detect.py nms(): sequential greedy semantics are kept exactly (a box survives iff no
-// earlier SURVIVING box overlaps it by more than thr); the suppression sweep of each survivor is
-// data-parallel over the workgroup, the survivor scan is a uniform LDS read per step.
+// earlier SURVIVING box overlaps it by more than thr); candidates are resolved in chunks of 64 (overlap
+// bits by ballots, the greedy pass over a chunk by one wave in registers) and a chunk's survivors suppress
+// the rest of the list in one data-parallel sweep.
 //
 // A list may be made of `nseg` segments of `seg_cap` slots, each with its own count (used to merge
 // the per-pyramid-level lists of one frame without a compaction pass).
@@ -72,22 +73,88 @@ __global__ __launch_bounds__(NMS_T) void sort_nms(const float* __restrict__ boxe
         alive[i] = 1;
     }
     __syncthreads();
-    int nkeep = 0;
-    for (int i = 0; i < n && nkeep < max_keep; ++i) {
-        if (!alive[i]) continue;                         // uniform: same LDS byte for every thread
-        if (tid == 0) keep[nkeep] = i;
-        ++nkeep;
-        const float4 bi = sb[i];
-        const float ai = sarea[i];
-        for (int j = i + 1 + tid; j < n; j += NMS_T) {
+    // Greedy NMS in CHUNKS of up to 64 candidates (exactly the sequential semantics): the next 64 entries that are still
+    // alive, in sorted order, are resolved among themselves - their 64 x 64 overlap bits by all waves (one ballot per
+    // row), the greedy pass over those bits by one wave in registers - and then ALL the chunk's survivors suppress the
+    // entries behind the chunk in ONE data-parallel sweep (a later entry stops at its first hit).  One survivor per
+    // pass (the first version) paid a barrier and a walk over every dead entry per survivor: a full 2 048-entry list
+    // with 256 survivors took 268 us, ~2 000 cycles per survivor.
+    constexpr int NW = NMS_T / 64;
+    __shared__ int wave_cnt[NW];
+    __shared__ int chunk_idx[64];
+    __shared__ unsigned long long cmask[64];
+    __shared__ float4 surv_b[64];
+    __shared__ float surv_a[64];
+    __shared__ int s_pos, s_ns;
+    const int lane = tid & 63, wave = tid >> 6;
+    auto overlaps = [&](const float4& bi, float ai, const float4& bj, float aj) {
+        float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+        float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+        float w = fmaxf(0.0f, xx2 - xx1 + 1.0f), h = fmaxf(0.0f, yy2 - yy1 + 1.0f);
+        float inter = w * h;
+        float o = mode == 1 ? inter / fminf(ai, aj) : inter / (ai + aj - inter);
+        return o > thr;
+    };
+    int nkeep = 0, pos = 0;
+    while (nkeep < max_keep && pos < n) {
+        // 1. the next (up to) 64 alive entries of the window [pos, pos + NMS_T), in order
+        const int j0 = pos + tid;
+        const bool a0 = j0 < n && alive[j0];
+        const unsigned long long bal = __ballot(a0);
+        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const int c = wave_cnt[w]; if (w < wave) base += c; total += c; }
+        const int rank = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (a0 && rank < 64) chunk_idx[rank] = j0;
+        if (total >= 64) { if (a0 && rank == 63) s_pos = j0 + 1; }
+        else if (tid == 0) s_pos = min(pos + NMS_T, n);
+        const int m = min(total, 64);
+        __syncthreads();
+        pos = s_pos;
+        if (m == 0) continue;                              // nothing alive in this window (uniform)
+        // 2. overlap bits inside the chunk: row a = bits of the later entries b > a that a would suppress
+        float4 cb = make_float4(0.f, 0.f, 0.f, 0.f); float ca = 1.f;
+        if (lane < m) { const int ci = chunk_idx[lane]; cb = sb[ci]; ca = sarea[ci]; }
+        for (int a = wave; a < m; a += NW) {
+            const int ci = chunk_idx[a];
+            const float4 ba = sb[ci]; const float aa = sarea[ci];
+            const unsigned long long row = __ballot(lane > a && lane < m && overlaps(ba, aa, cb, ca));
+            if (lane == 0) cmask[a] = row;
+        }
+        __syncthreads();
+        // 3. greedy pass over the chunk, one wave, bits in registers
+        if (wave == 0) {
+            const unsigned long long mine = lane < m ? cmask[lane] : 0ull;
+            const unsigned lo = (unsigned)mine, hi = (unsigned)(mine >> 32);
+            unsigned long long removed = 0ull, kept = 0ull;
+            int cnt = nkeep;
+            for (int a = 0; a < m && cnt < max_keep; ++a) {
+                if (!((removed >> a) & 1ull)) {
+                    kept |= 1ull << a;
+                    removed |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, a) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)lo, a);
+                    ++cnt;
+                }
+            }
+            if (lane == 0) s_ns = cnt - nkeep;
+            if (lane < m && ((kept >> lane) & 1ull)) {
+                const int k = __popcll(kept & ((1ull << lane) - 1ull));
+                const int ci = chunk_idx[lane];
+                keep[nkeep + k] = ci;
+                surv_b[k] = cb; surv_a[k] = ca;
+            }
+        }
+        __syncthreads();
+        const int ns = s_ns;
+        nkeep += ns;
+        if (nkeep >= max_keep) break;
+        // 4. the chunk's survivors against everything behind the chunk (entries before `pos` are never looked at again)
+        for (int j = pos + tid; j < n; j += NMS_T) {
             if (!alive[j]) continue;
-            const float4 bj = sb[j];
-            float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
-            float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
-            float w = fmaxf(0.0f, xx2 - xx1 + 1.0f), h = fmaxf(0.0f, yy2 - yy1 + 1.0f);
-            float inter = w * h;
-            float o = mode == 1 ? inter / fminf(ai, sarea[j]) : inter / (ai + sarea[j] - inter);
-            if (o > thr) alive[j] = 0;
+            const float4 bj = sb[j]; const float aj = sarea[j];
+            for (int k = 0; k < ns; ++k)
+                if (overlaps(surv_b[k], surv_a[k], bj, aj)) { alive[j] = 0; break; }
         }
         __syncthreads();
     }
