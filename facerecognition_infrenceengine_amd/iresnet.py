@@ -35,7 +35,8 @@ LOW_BATCH = 8
 MAX_PLAN_STREAMS = 8
 # from this many faces up the stride-1 blocks of the 14x14 stage run as ONE launch with the image resident in LDS
 # (fr_conv_stage14_f16: one workgroup per image, one image per CU); below, the per-layer path fills the CUs better
-STAGE14_MIN_BATCH = 128
+# (measured r100 forward, stage / layer by layer: 128 faces 4.62 / 4.44 ms, 160: 5.16 / 5.74, 192: 5.49 / 6.17, 256: 6.8 / 7.6)
+STAGE14_MIN_BATCH = 144
 
 
 def _bn_fold(st, prefix, n, conv=None):
