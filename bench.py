@@ -468,7 +468,8 @@ def main():
             traffic = max(hits, key=lambda v: v.get("dispatches", 0))["hbm_bytes_per_launch_corrected"]
     except (OSError, KeyError, ValueError):
         pass
-    peak = MFMA_PEAK_TFLOPS_F8 if dom.startswith("conv_halo") and dom.endswith(", true, 8, 0>") else MFMA_PEAK_TFLOPS
+    is_f8 = dom.startswith("conv_stage14_f8") or (dom.startswith("conv_halo") and dom.endswith(", true, 8, 0>"))
+    peak = MFMA_PEAK_TFLOPS_F8 if is_f8 else MFMA_PEAK_TFLOPS
     roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_source": f"{PMC_FILE}: rocprofv3 --pmc passes of tools/pmc_traffic.py (separate run; counters "

@@ -125,10 +125,15 @@ __global__ __launch_bounds__(512, 2) void conv_stage14_kernel(StageP p) {
         }
     }
 
+    // Everything from here on exists in TWO copies, one per wave role (WP = wave >> 2: pixel group, cout tiles of the
+    // shared pixel tile, place of the weight DMA in a step): no wave-uniform branches inside the unrolled steps (the
+    // fp8 twin spilled 480 VGPRs with them).
+    auto run = [&](auto wp_tag) {
+    constexpr int WP = decltype(wp_tag)::value;
     // A fragment: row (cout) fr of a 16-cout tile, 16-B chunk fq ^ key(row)
     const int a_lane = fr * 64 + ((fq ^ (((fr >> 3) & 1) << 1)) << 4);
     const int a_own = wn * 4096 + a_lane;                            // + i * 1024: cout tile i of the wave's 64 couts
-    const int px0 = wp * 96 + fr;                                    // pixel of tile 0; tile j: + 16 j; the shared 13th tile: 192 + fr
+    const int px0 = WP * 96 + fr;                                    // pixel of tile 0; tile j: + 16 j; the shared 13th tile: 192 + fr
 
     float4v acc[6][4], accx[2];
     // fragments: the weights (A) are double-buffered across steps; a pixel fragment (B) is re-read for the NEXT step
@@ -195,10 +200,9 @@ __global__ __launch_bounds__(512, 2) void conv_stage14_kernel(StageP p) {
         // the partner has the matrix pipe to itself; the partner issues its pieces behind its 18th MFMA (about when the
         // first wave's pieces are out), while the first wave has the pipe (stamps: DMA in the middle of both streams
         // 1 470 cycles per step, first / last 1 180, first / 18th: see DESIGN.md).
-        if (wp == 0 && !(ABL & 4)) { issue_w(k % 3); S14_PIN(); }
-        // the shared 13th pixel tile: this wave's cout tiles 2 wp, 2 wp + 1 of its own four - the same weight fragments
-        if (wp == 0) { accx[0] = mm(ac[0], bx, accx[0]); accx[1] = mm(ac[1], bx, accx[1]); }
-        else { accx[0] = mm(ac[2], bx, accx[0]); accx[1] = mm(ac[3], bx, accx[1]); }
+        if constexpr (WP == 0 && !(ABL & 4)) { issue_w(k % 3); S14_PIN(); }
+        // the shared 13th pixel tile: this wave's cout tiles 2 WP, 2 WP + 1 of its own four - the same weight fragments
+        accx[0] = mm(ac[2 * WP], bx, accx[0]); accx[1] = mm(ac[2 * WP + 1], bx, accx[1]);
         S14_PIN();
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void conv_stage14_kernel(StageP p) {
                 b[5] = rd_b(ng, 5);
             }
             S14_PIN();
-            if (j == 3 && wp == 1 && !(ABL & 4)) { issue_w(k % 3); S14_PIN(); }
+            if constexpr (WP == 1 && !(ABL & 4)) { if (j == 3) { issue_w(k % 3); S14_PIN(); } }
         }
     };
 
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void conv_stage14_kernel(StageP p) {
         if (STAMPS && conv) se += tC - tB;                           // the previous conv's epilogue
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
-        fre = lane_e & 15; fqe = lane_e >> 4; px0e = wp * 96 + fre;
+        fre = lane_e & 15; fqe = lane_e >> 4; px0e = WP * 96 + fre;
         issue_prm(conv, lane_e);                                     // read in this conv's epilogue, 72 steps from here
         // prologue: fragments of the conv's first step (its slot, 0, landed before the previous conv's last barrier)
         set_tap(-1, -1);
@@ -298,8 +302,8 @@ __global__ __launch_bounds__(512, 2) void conv_stage14_kernel(StageP p) {
             rowoff[j] = wn * S14_PLANE + pxr * 128 + (fqe & 1) * 8;
             key[j] = pxr & 7;
         }
-        const int co_own = wn * 64 + fqe * 4, co_sh = wn * 64 + wp * 32 + fqe * 4;      // + 16 per cout tile
-        const int ch_own = fqe >> 1, ch_sh = wp * 4 + (fqe >> 1);                       // 16-B chunk inside the plane row: + 2 per cout tile
+        const int co_own = wn * 64 + fqe * 4, co_sh = wn * 64 + WP * 32 + fqe * 4;      // + 16 per cout tile
+        const int ch_own = fqe >> 1, ch_sh = WP * 4 + (fqe >> 1);                       // 16-B chunk inside the plane row: + 2 per cout tile
         // PRELU is a compile-time flag of two copies of the tile loop: a block's second conv has none (slope 1)
         auto tiles = [&](auto prelu_tag) {
             constexpr bool FIRST = decltype(prelu_tag)::value;       // first conv of a block: PReLU, and the residual refill
@@ -347,6 +351,8 @@ __global__ __launch_bounds__(512, 2) void conv_stage14_kernel(StageP p) {
             }
         }
     }
+    };
+    if (wp == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     S14_STAMP(tC);
     if (STAMPS) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rB)::"memory");

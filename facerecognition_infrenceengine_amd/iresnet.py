@@ -224,6 +224,7 @@ class IResNetHIP:
         self.profile = None          # bench.py: list collecting (kernel variant, flops, ev0, ev1) per conv launch
         self.fp8 = False             # enable_fp8(): eligible body convs run on the fp8 matrix cores
         self.use_stage14 = True      # False: the 14x14 stage runs layer by layer whatever the batch (A/B, tests)
+        self.stage14_f8 = None       # enable_fp8(): the run's fp8 form (fr_conv_stage14_f8)
         self._calib = None
 
     # ---- the 14x14 stage as one launch (fr_conv_stage14_f16)
@@ -334,7 +335,57 @@ class IResNetHIP:
             c.bias8 = b9.reshape(9 * c.cout).to(torch.float32).contiguous().to(self.device)
             n += 1
         self.fp8 = n > 0
+        self._pack_stage14_f8()
         return n
+
+    def _pack_stage14_f8(self):
+        """fp8 form of the 14x14 run (fr_conv_stage14_f8) when every conv of the run was switched to fp8: the e4m3 weights
+        as one pre-swizzled stream + f32 [14][256] parameters per conv (oscale, 1 / oscale, nine border-class biases,
+        PReLU slope, the NEXT conv's input centre mu and 1 / sx: a conv's epilogue writes its consumer's codes)."""
+        self.stage14_f8 = None
+        st = self.stage14
+        if st is None or not self.fp8:
+            return
+        run = [self.blocks[st["first"] + k] for k in range(st["n"])]
+        convs = [c for c1, c2, _ in run for c in (c1, c2)]
+        if any(c.oscale is None or c.mu is None for c in convs):
+            return
+        after = self.blocks[st["first"] + st["n"]][0] if st["first"] + st["n"] < len(self.blocks) else None
+        if after is not None and (after.oscale is None or after.cin != 256):
+            after = None                                  # the run's consumer is not an fp8 conv: the last codes are unused
+        per = self.lib.fr_conv_stage14_f8_weight_bytes(1)
+        rows = self.lib.fr_conv_stage14_f8_param_floats() // 256
+        stream = torch.empty(len(convs) * per, dtype=torch.uint8, device=self.device)
+        prm = torch.zeros((len(convs), rows, 256), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            for k, c in enumerate(convs):
+                self.lib.fr_conv_stage14_f8_pack(_lib.ptr(c.w8), _lib.ptr(stream[k * per:]), _lib.stream_ptr())
+                nxt = convs[k + 1] if k + 1 < len(convs) else after
+                prm[k, 0] = c.oscale
+                prm[k, 1] = (1.0 / c.oscale.double()).to(torch.float32)
+                prm[k, 2:11] = c.bias8.reshape(9, 256)
+                prm[k, 11] = c.slope if c.slope is not None else 1.0
+                if nxt is not None:
+                    prm[k, 12] = nxt.mu
+                    prm[k, 13, 0] = 1.0 / nxt.sx
+                else:
+                    prm[k, 13, 0] = 1.0
+            torch.cuda.synchronize(self.device)
+        self.stage14_f8 = {"w": stream, "prm": prm.contiguous()}
+
+    def _run_stage14_f8(self, h, h8, B):
+        st, f8 = self.stage14, self.stage14_f8
+        y = torch.empty_like(h)
+        args = (_lib.ptr(h8), _lib.ptr(h), _lib.ptr(y), _lib.ptr(f8["w"]), _lib.ptr(f8["prm"]), B, st["n"], _lib.stream_ptr())
+        if self.profile is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.lib.fr_conv_stage14_f8(*args)
+            e1.record()
+            self.profile.append(("conv_stage14_f8_kernel<0>", 2.0 * B * 196 * 256 * 2304 * 2 * st["n"], e0, e1))
+        else:
+            self.lib.fr_conv_stage14_f8(*args)
+        return y
 
     def _calib_observe(self, c, x, H):
         """calibration forward: statistics of the tensor ``x`` (f16 NHWC) an fp8 candidate reads"""
@@ -581,11 +632,15 @@ class IResNetHIP:
         h8 = None                                  # fp8 copy of h, scaled for the conv that will read it (or None)
         nb = len(self.blocks)
         use_stage = (self.stage14 is not None and self.use_stage14 and B >= STAGE14_MIN_BATCH and taps is None
-                     and self._calib is None and not self.fp8)
+                     and self._calib is None and (not self.fp8 or self.stage14_f8 is not None))
         for bi_, (c1, c2, sc) in enumerate(self.blocks):
             if use_stage and self.stage14["first"] <= bi_ < self.stage14["first"] + self.stage14["n"]:
-                if bi_ == self.stage14["first"]:
-                    h = self._run_stage14(h, B)        # all n blocks; the loop skips the rest of the run
+                if bi_ == self.stage14["first"]:       # all n blocks in one launch; the loop skips the rest of the run
+                    if self.fp8:
+                        h = self._run_stage14_f8(h, h8 if h8 is not None else self._quantise(h, c1), B)
+                        h8 = None                      # the run's consumer quantises the f16 output itself
+                    else:
+                        h = self._run_stage14(h, B)
                 continue
             self._calib_observe(c1, h, H)              # enable_fp8(): statistics of the tensors the candidates read
             f1 = self.fp8 and c1.oscale is not None

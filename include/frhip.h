@@ -185,6 +185,21 @@ size_t fr_conv_stage14_weight_bytes(int nconv);
 int fr_conv_stage14_pack(const void* w, void* out, fr_stream_t stream);
 int fr_conv_stage14_f16(const void* x, void* y, const void* wstream, const float* params, int B, int nblocks,
                         fr_stream_t stream);
+/* The fp8 twin of fr_conv_stage14_f16 (BASELINE config C5): the same run of residual blocks on
+ * v_mfma_scale_f32_16x16x128_f8f6f4, the conv inputs as centred e4m3 codes resident in LDS (conv_stage14_f8.hip).  Math and
+ * operation order of fr_conv_nhwc_f8 per conv: acc * oscale + 9-class bias -> PReLU -> (+ f16 residual) -> one rounding to
+ * f16 -> the next conv's codes fp8((y - mu_next) * inv_sx_next).  x8: e4m3 codes NHWC [B,14,14,256] of the first conv's
+ * input, x16: the same tensor in f16 (the first block's residual), y16: f16, receives every block's output in turn (the
+ * residual stream goes through HBM: it does not fit beside the codes and the weight ring), x16 != y16.  wstream: the
+ * convs' e4m3 weights [256][9*256] re-ordered by fr_conv_stage14_f8_pack into 18 x 32 KB slot images each
+ * (fr_conv_stage14_f8_weight_bytes(1) bytes per conv).  params: f32 [2*nblocks][14][256]: row 0 oscale, 1 its reciprocal,
+ * 2..10 the nine border-class biases, 11 the PReLU slope (1.0 = none), 12 mu of the NEXT conv's input, 13 whose first
+ * element is 1 / sx of the next conv (fr_conv_stage14_f8_param_floats() floats per conv). */
+size_t fr_conv_stage14_f8_weight_bytes(int nconv);
+size_t fr_conv_stage14_f8_param_floats(void);
+int fr_conv_stage14_f8_pack(const void* w8, void* out, fr_stream_t stream);
+int fr_conv_stage14_f8(const void* x8, const void* x16, void* y16, const void* wstream, const float* params, int B,
+                       int nblocks, fr_stream_t stream);
 /* Calibration-time weight rounding for fr_conv_nhwc_f8 (GPTQ, Frantar et al. 2022): W f64 [rows][K] folded weights,
  * U f64 [K][K] = upper Cholesky factor of the inverse of the second-moment matrix of the conv's input patches (K order
  * as W's columns), sw f32 [rows] the per-row scale.  Q f32 [rows][K] receives values ON THE e4m3 GRID (w8 = Q exactly):

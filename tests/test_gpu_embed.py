@@ -464,6 +464,35 @@ def test_r100_fp8_embedding_vs_golden(golden):
     assert not torch.isnan(e8).any()
 
 
+def test_stage14_f8_path_equals_layer_path_and_meets_the_bound():
+    """From 144 faces up the fp8 convs of the 14x14 run execute as ONE launch (fr_conv_stage14_f8: codes resident in LDS,
+    residual stream through HBM).  Same arithmetic per conv as fr_conv_nhwc_f8, another summation order: the embeddings
+    must agree with the layer-by-layer fp8 path to well below the fp8 noise itself, and stay inside north_star's bound
+    against the fp32 oracle (checked on the first 8 faces of the batch: a face's embedding does not depend on its batch
+    mates)."""
+    from facerecognition_infrenceengine_amd import weights
+    from facerecognition_infrenceengine_amd.iresnet import IResNetHIP
+    from oracle import nets as onets
+    st = weights.synth_iresnet_state("r100", seed=1234)
+    net = IResNetHIP(st, "r100", "cuda:0")
+    xs = _structured_crops(150, 51)
+    assert net.enable_fp8(nchw_to_nhwc8(_structured_crops(64, 32))) == 63
+    assert net.stage14_f8 is not None
+    x = nchw_to_nhwc8(xs)
+    e_stage, n_stage = net.forward(x)
+    net.use_stage14 = False
+    e_layer, _ = net.forward(x)
+    net.use_stage14 = True
+    cos = torch.nn.functional.cosine_similarity(e_stage, e_layer)
+    assert float((1 - cos).max()) < 1e-4, float((1 - cos).max())
+    ref = onets.iresnet_forward(st, xs[:8], weights.IRESNET_LAYERS["r100"]).numpy()
+    got = e_stage[:8].cpu().numpy()
+    c = (got * ref).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(ref, axis=1))
+    assert (1 - c).max() < 1e-3, 1 - c
+    assert not torch.isnan(e_stage).any()
+    np.testing.assert_allclose(np.linalg.norm(n_stage.cpu().numpy(), axis=1), 1.0, atol=1e-6)
+
+
 def test_fp8_ids_equal_oracle_ids_after_match():
     """C5 end of the path: fp8 embeddings -> exact gallery match.  Gallery rows are the ORACLE's (fp32) embeddings of
     64 faces plus 5 000 random rows; every fp8 query must match its own face's row, as the oracle query does."""
