@@ -466,11 +466,12 @@ def test_r100_fp8_embedding_vs_golden(golden):
 
 def test_stage14_f8_path_equals_layer_path_and_meets_the_bound():
     """From 144 faces up the fp8 convs of the 14x14 run execute as ONE launch (fr_conv_stage14_f8: codes resident in LDS,
-    residual stream through HBM).  Same arithmetic per conv as fr_conv_nhwc_f8, another summation order: the embeddings
-    must agree with the layer-by-layer fp8 path to well below the fp8 noise itself, and stay inside north_star's bound
-    against the fp32 oracle (checked on the first 8 faces of the batch: a face's embedding does not depend on its batch
-    mates)."""
-    from facerecognition_infrenceengine_amd import weights
+    residual stream through HBM).  Same arithmetic per conv as fr_conv_nhwc_f8, another summation order:
+    (1) ONE block through the stage kernel equals the two per-layer fp8 convs to f16 rounding ties (the sharp check: rounding
+    to e4m3 is discontinuous, so over 58 convs two valid summation orders drift apart by a good part of the fp8 noise
+    itself); (2) the embeddings stay inside north_star's bound against the fp32 oracle (first 8 faces of the batch: a face's
+    embedding does not depend on its batch mates) and near the layer-by-layer fp8 path."""
+    from facerecognition_infrenceengine_amd import _lib, weights
     from facerecognition_infrenceengine_amd.iresnet import IResNetHIP
     from oracle import nets as onets
     st = weights.synth_iresnet_state("r100", seed=1234)
@@ -479,16 +480,39 @@ def test_stage14_f8_path_equals_layer_path_and_meets_the_bound():
     assert net.enable_fp8(nchw_to_nhwc8(_structured_crops(64, 32))) == 63
     assert net.stage14_f8 is not None
     x = nchw_to_nhwc8(xs)
+    grabbed = {}
+    orig = net._run_stage14_f8
+
+    def grab(h, h8, B):
+        grabbed["h"], grabbed["h8"] = h.clone(), h8.clone()
+        return orig(h, h8, B)
+    net._run_stage14_f8 = grab
     e_stage, n_stage = net.forward(x)
+    net._run_stage14_f8 = orig
+    # (1) one block: stage kernel vs the two per-layer calls on the run's real input, weights and parameters
+    h, h8, B = grabbed["h"], grabbed["h8"], 150
+    c1, c2, _ = net.blocks[net.stage14["first"]]
+    y1 = torch.empty_like(h)
+    net.lib.fr_conv_stage14_f8(_lib.ptr(h8), _lib.ptr(h), _lib.ptr(y1), _lib.ptr(net.stage14_f8["w"]), _lib.ptr(net.stage14_f8["prm"]),
+                               B, 1, _lib.stream_ptr())
+    _, mid8 = net._conv_f8(h8, c1, B, 14, 14, want16=False, nxt=c2)
+    y2, _ = net._conv_f8(mid8, c2, B, 14, 14, residual=h, want16=True)
+    torch.cuda.synchronize()
+    d = (y1.float() - y2.float()).abs()
+    scale = y2.float().abs().max().item()
+    assert d.max().item() <= 4e-3 * scale and d.mean().item() < 2e-5 * scale, (d.max().item(), d.mean().item(), scale)
+    # (2) the whole net
     net.use_stage14 = False
     e_layer, _ = net.forward(x)
     net.use_stage14 = True
     cos = torch.nn.functional.cosine_similarity(e_stage, e_layer)
-    assert float((1 - cos).max()) < 1e-4, float((1 - cos).max())
     ref = onets.iresnet_forward(st, xs[:8], weights.IRESNET_LAYERS["r100"]).numpy()
-    got = e_stage[:8].cpu().numpy()
-    c = (got * ref).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(ref, axis=1))
-    assert (1 - c).max() < 1e-3, 1 - c
+    got, lay = e_stage[:8].cpu().numpy(), e_layer[:8].cpu().numpy()
+    cs = (got * ref).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(ref, axis=1))
+    cl = (lay * ref).sum(1) / (np.linalg.norm(lay, axis=1) * np.linalg.norm(ref, axis=1))
+    print(f"\nfp8 stage path: 1-cos vs oracle max {(1 - cs).max():.3e} (layer path {(1 - cl).max():.3e}); stage vs layer path max {float((1 - cos).max()):.3e}")
+    assert (1 - cs).max() < 1e-3, 1 - cs
+    assert float((1 - cos).max()) < 1.5e-3
     assert not torch.isnan(e_stage).any()
     np.testing.assert_allclose(np.linalg.norm(n_stage.cpu().numpy(), axis=1), 1.0, atol=1e-6)
 
