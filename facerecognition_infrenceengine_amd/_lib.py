@@ -70,6 +70,9 @@ SIGNATURES = {
     "fr_conv_stage14_weight_bytes": (_Z, [_I]),
     "fr_conv_stage14_pack": (_I, [_P, _P, _P]),
     "fr_conv_stage14_f16": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "fr_conv_stage28_weight_bytes": (_Z, [_I]),
+    "fr_conv_stage28_pack": (_I, [_P, _P, _P]),
+    "fr_conv_stage28_f16": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "fr_conv_stage14_f8_weight_bytes": (_Z, [_I]),
     "fr_conv_stage14_f8_param_floats": (_Z, []),
     "fr_conv_stage14_f8_pack": (_I, [_P, _P, _P]),

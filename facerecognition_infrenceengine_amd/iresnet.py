@@ -37,6 +37,7 @@ MAX_PLAN_STREAMS = 8
 # (fr_conv_stage14_f16: one workgroup per image, one image per CU); below, the per-layer path fills the CUs better
 # (measured r100 forward, stage / layer by layer: 128 faces 4.62 / 4.44 ms, 160: 5.16 / 5.74, 192: 5.49 / 6.17, 256: 6.8 / 7.6)
 STAGE14_MIN_BATCH = 144
+STAGE28_MIN_BATCH = 144     # fr_conv_stage28_f16: one workgroup per face, as the 14x14 stage kernel
 
 
 def _bn_fold(st, prefix, n, conv=None):
@@ -214,6 +215,7 @@ class IResNetHIP:
                 sc = _Conv(_pack_w(ds["w"]), ds["bias"], None, ds["cin"], ds["cout"], 1, ds["stride"], 0, 0, dev)
             self.blocks.append((c1, c2, sc))
         self._pack_stage14()
+        self._pack_stage28()
         self.fc_w = f["fc_w"].to(torch.float16).contiguous().to(dev)
         self.fc_bias = f["fc_bias"].to(torch.float32).contiguous().to(dev)
         self.flops_per_face = self._count_flops()
@@ -223,6 +225,7 @@ class IResNetHIP:
         self._plan_limit_logged = False
         self.profile = None          # bench.py: list collecting (kernel variant, flops, ev0, ev1) per conv launch
         self.fp8 = False             # enable_fp8(): eligible body convs run on the fp8 matrix cores
+        self.use_stage28 = True      # False: the 28x28 stage runs layer by layer whatever the batch (A/B, tests)
         self.use_stage14 = True      # False: the 14x14 stage runs layer by layer whatever the batch (A/B, tests)
         self.stage14_f8 = None       # enable_fp8(): the run's fp8 form (fr_conv_stage14_f8)
         self._calib = None
@@ -254,6 +257,48 @@ class IResNetHIP:
                     prm[2 * k + j, 9] = c.slope if c.slope is not None else 1.0
             torch.cuda.synchronize(self.device)
         self.stage14 = {"first": best[0], "n": len(best), "w": stream, "prm": prm.contiguous()}
+
+    # ---- the 28x28 stage's stride-1 blocks as one launch (fr_conv_stage28_f16)
+    def _pack_stage28(self):
+        """The longest run of consecutive stride-1 128 -> 128 blocks (r100: blocks 4..15, the 12 blocks behind stage 2's
+        entry block): weights as one pre-swizzled stream in kernel order + [10][128] f32 parameters per conv."""
+        self.stage28 = None
+        run, best = [], []
+        for i, (c1, c2, sc) in enumerate(self.blocks):
+            ok = sc is None and c1.cin == 128 and c1.cout == 128 and c2.stride == 1 and c2.cout == 128
+            run = run + [i] if ok else []
+            if len(run) > len(best):
+                best = run
+        if len(best) < 2:
+            return
+        nconv = 2 * len(best)
+        per = self.lib.fr_conv_stage28_weight_bytes(1) // 2
+        stream = torch.empty(nconv * per, dtype=torch.float16, device=self.device)
+        prm = torch.empty((nconv, 10, 128), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            for k, i in enumerate(best):
+                c1, c2, _ = self.blocks[i]
+                for j, c in enumerate((c1, c2)):
+                    self.lib.fr_conv_stage28_pack(_lib.ptr(c.w), _lib.ptr(stream[(2 * k + j) * per:]), _lib.stream_ptr())
+                    prm[2 * k + j, :9] = c.bias.reshape(9, 128) if c.bias_mode == 1 else c.bias[None, :]
+                    prm[2 * k + j, 9] = c.slope if c.slope is not None else 1.0
+            torch.cuda.synchronize(self.device)
+        self.stage28 = {"first": best[0], "n": len(best), "w": stream, "prm": prm.contiguous()}
+
+    def _run_stage28(self, h, B, nblocks):
+        """The run's first ``nblocks`` blocks, in place: ``h`` (the run's input, nobody else's) comes back as their output."""
+        st = self.stage28
+        mid = torch.empty_like(h)
+        args = (_lib.ptr(h), _lib.ptr(mid), _lib.ptr(st["w"]), _lib.ptr(st["prm"]), B, nblocks, _lib.stream_ptr())
+        if self.profile is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.lib.fr_conv_stage28_f16(*args)
+            e1.record()
+            self.profile.append(("conv_stage28_kernel", 2.0 * B * 784 * 128 * 1152 * 2 * nblocks, e0, e1))
+        else:
+            self.lib.fr_conv_stage28_f16(*args)
+        return h
 
     def _run_stage14(self, h, B):
         st = self.stage14
@@ -633,7 +678,21 @@ class IResNetHIP:
         nb = len(self.blocks)
         use_stage = (self.stage14 is not None and self.use_stage14 and B >= STAGE14_MIN_BATCH and taps is None
                      and self._calib is None and (not self.fp8 or self.stage14_f8 is not None))
+        # the 28x28 run: its leading blocks that hold no fp8 conv (enable_fp8 "accurate": all but the last two)
+        s28_first = s28_n = 0
+        if (self.stage28 is not None and self.use_stage28 and B >= STAGE28_MIN_BATCH and taps is None and self._calib is None):
+            s28_first = self.stage28["first"]
+            for c1, c2, _ in self.blocks[s28_first:s28_first + self.stage28["n"]]:
+                if self.fp8 and (c1.oscale is not None or c2.oscale is not None):
+                    break
+                s28_n += 1
+            if s28_n < 2:
+                s28_n = 0
         for bi_, (c1, c2, sc) in enumerate(self.blocks):
+            if s28_first <= bi_ < s28_first + s28_n:
+                if bi_ == s28_first:
+                    h = self._run_stage28(h, B, s28_n)
+                continue
             if use_stage and self.stage14["first"] <= bi_ < self.stage14["first"] + self.stage14["n"]:
                 if bi_ == self.stage14["first"]:       # all n blocks in one launch; the loop skips the rest of the run
                     if self.fp8:

@@ -133,6 +133,8 @@ class MTCNNHIP:
         self._tls = threading.local()      # per-thread launch stream: detect_batch is re-entrant across threads
         self._one_stream = os.environ.get("FR_DET_ONE_STREAM") == "1"      # profiling: per-kernel times add up
         self._nsides = int(os.environ.get("FR_DET_SIDES", "1"))
+        self.phase_marks = None            # tools: a list -> (name, event on the caller's stream) at the cascade's phase ends
+        self.merged_level_nms = False      # True: the per-level NMS of ALL levels as one launch behind the pyramid
         d = self.device
         p, r, o = ({k: v.detach().float().cpu() for k, v in s.items()} for s in (pstate, rstate, ostate))
         self.p1 = _MConv(0, p["conv1.weight"], p["conv1.bias"], p["prelu1.weight"], d)
@@ -284,6 +286,12 @@ class MTCNNHIP:
         x, h, w = self._dconv(x, self.o6, B, 1, 1, **k)
         return x.reshape(B, 16)
 
+    def _mark(self, name):
+        if self.phase_marks is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.phase_marks.append((name, e))
+
     # ---- cascade
     def detect_batch(self, frames, trace=None, level_streams=None):
         """frames: uint8 [N,H,W,3] BGR device tensor (contiguous).
@@ -300,6 +308,7 @@ class MTCNNHIP:
         lib, t0, t1, t2 = self.lib, *self.thresholds
         with torch.cuda.device(self.device):
             self._s = _lib.stream_ptr()
+            self._mark("start")
             scales = pyramid_scales(H, W, self.minsize, self.factor)
             nlev = len(scales)
             if nlev == 0:                       # frame smaller than one 12-px cell at the coarsest usable scale
@@ -336,7 +345,7 @@ class MTCNNHIP:
                     # per-level NMS 0.5 -> keep_scale survivors.  Batches: right behind the level's own kernels on the
                     # level's stream, so the one-workgroup-per-list sorts (latency-bound) run under the other levels'
                     # P-Net.  Single frames are launch-bound: one launch for all levels after the loop instead.
-                    if N >= 8:
+                    if N >= 8 and not self.merged_level_nms:
                         self._nms(lb[li], ls[li], lr[li], 4, lc[li], N, 1, cs, 0, 0.5, 0, ksz, out=(kb[li], ks[li], ka[li], kc[li]))
                     if trace is not None:
                         trace.setdefault("pnet_head", []).append(head)
@@ -344,11 +353,13 @@ class MTCNNHIP:
             for side in sides:
                 main.wait_stream(side)
             self._s = _lib.stream_ptr()
-            if N < 8:
+            self._mark("pnet")
+            if N < 8 or self.merged_level_nms:
                 self._nms(lb, ls, lr, 4, lc, nlev * N, 1, cs, 0, 0.5, 0, ksz, out=(kb, ks, ka, kc))
             # cross-level NMS 0.7 -> cap_p
             b1, s1, a1, c1 = self._nms(kb, ks, ka, 4, kc, N, nlev, self.keep_scale, 1, 0.7, 0, self.cap_p)
             lib.fr_box_refine(_lib.ptr(b1), _lib.ptr(a1), 4, _lib.ptr(c1), N, self.cap_p, 0, self._s)
+            self._mark("stage1_nms")
             if trace is not None:
                 trace.update(stage1_boxes=b1, stage1_scores=s1, stage1_counts=c1)
             # ---- stage 2
@@ -367,6 +378,7 @@ class MTCNNHIP:
                                 _lib.ptr(ss), _lib.ptr(sa), 4, _lib.ptr(sc), _lib.ptr(prob2), self._s)
             b2, s2, a2, c2 = self._nms(sb, ss, sa, 4, sc, N, 1, self.cap_p, 0, 0.7, 0, self.cap_r)
             lib.fr_box_refine(_lib.ptr(b2), _lib.ptr(a2), 4, _lib.ptr(c2), N, self.cap_r, 1, self._s)
+            self._mark("stage2")
             if trace is not None:
                 trace.update(rnet_crops=crops, rnet_head=head2, rnet_prob=prob2, stage2_boxes=b2, stage2_scores=s2,
                              stage2_counts=c2)
@@ -385,6 +397,7 @@ class MTCNNHIP:
                                 _lib.ptr(ts), _lib.ptr(ta), 14, _lib.ptr(tc), _lib.ptr(prob3), self._s)
             lib.fr_box_refine(_lib.ptr(tb), _lib.ptr(ta), 14, _lib.ptr(tc), N, self.cap_r, 2, self._s)
             b3, s3, a3, c3 = self._nms(tb, ts, ta, 14, tc, N, 1, self.cap_r, 0, 0.7, 1, self.cap_o)
+            self._mark("stage3")
             if trace is not None:
                 trace.update(onet_head=head3, onet_prob=prob3)
             # aux = (reg4, (x1,y1)..(x5,y5)): kps is a strided view, no copy

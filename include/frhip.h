@@ -185,6 +185,17 @@ size_t fr_conv_stage14_weight_bytes(int nconv);
 int fr_conv_stage14_pack(const void* w, void* out, fr_stream_t stream);
 int fr_conv_stage14_f16(const void* x, void* y, const void* wstream, const float* params, int B, int nblocks,
                         fr_stream_t stream);
+/* The run of stride-1 128 -> 128 residual blocks of IResNet's 28x28 stage (r100: 12 blocks = 24 convs; embed half of
+ * FaceAnalysis.get, /root/reference/infrenceServer.py:528) as ONE launch, one workgroup per face walking its own map through
+ * all the convs (conv_stage28.hip): half an image per pass, the half's input halo in LDS, weights streaming, outputs
+ * straight from the accumulators to HBM, read back by the same workgroup.  Same math as the blocks run through
+ * fr_conv_nhwc_f16.  x: f16 [B][28][28][128], OVERWRITTEN with the run's output; mid: scratch of the same size; wstream: the
+ * convs' weights in kernel order, each re-ordered by fr_conv_stage28_pack from the [128][9*128] f16 layout into 36 x 8 KB
+ * slot images (fr_conv_stage28_weight_bytes(1) bytes per conv); params: f32 [2*nblocks][10][128] = 9 border-class biases
+ * (a plain bias nine times) + PReLU slope (1.0 = none). */
+size_t fr_conv_stage28_weight_bytes(int nconv);
+int fr_conv_stage28_pack(const void* w, void* out, fr_stream_t stream);
+int fr_conv_stage28_f16(void* x, void* mid, const void* wstream, const float* params, int B, int nblocks, fr_stream_t stream);
 /* The fp8 twin of fr_conv_stage14_f16 (BASELINE config C5): the same run of residual blocks on
  * v_mfma_scale_f32_16x16x128_f8f6f4, the conv inputs as centred e4m3 codes resident in LDS (conv_stage14_f8.hip).  Math and
  * operation order of fr_conv_nhwc_f8 per conv: acc * oscale + 9-class bias -> PReLU -> (+ f16 residual) -> one rounding to

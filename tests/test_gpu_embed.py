@@ -258,6 +258,80 @@ def test_stage14_kernel_vs_torch(lib, B, nblocks):
     assert d.max().item() <= 2e-3 * ref.abs().max().item() and d.mean().item() < 1e-4 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("B,nblocks", [(1, 1), (3, 2), (5, 3)])
+def test_stage28_kernel_vs_torch(lib, B, nblocks):
+    """fr_conv_stage28_f16 (one workgroup walks a face through all convs of the 28x28 run, half an image per pass, maps
+    through HBM, in place) against plain torch fp32 on the same f16-rounded operands with the kernel's roundings, and
+    against the per-layer kernels."""
+    from facerecognition_infrenceengine_amd import _lib
+    g = torch.Generator().manual_seed(280 + B)
+    x = torch.randn((B, 28, 28, 128), generator=g).to(torch.float16)
+    per = lib.fr_conv_stage28_weight_bytes(1) // 2
+    stream = torch.empty(2 * nblocks * per, dtype=torch.float16, device="cuda")
+    prm = torch.empty((2 * nblocks, 10, 128), dtype=torch.float32)
+    ws = []
+    rc = torch.ones(28, dtype=torch.long); rc[0] = 0; rc[-1] = 2
+    h = x.float().permute(0, 3, 1, 2)
+    for k in range(nblocks):
+        w1 = (torch.randn((128, 3, 3, 128), generator=g) * (2.0 / 1152) ** 0.5).to(torch.float16)
+        w2 = (torch.randn((128, 3, 3, 128), generator=g) * (0.3 / 1152) ** 0.5).to(torch.float16)
+        b9 = torch.randn((3, 3, 128), generator=g) * 0.3
+        sl = torch.rand(128, generator=g) * 0.5
+        b2 = torch.randn(128, generator=g) * 0.1
+        prm[2 * k, :9] = b9.reshape(9, 128); prm[2 * k, 9] = sl
+        prm[2 * k + 1, :9] = b2[None, :]; prm[2 * k + 1, 9] = 1.0
+        for j, w in enumerate((w1, w2)):
+            wd = w.reshape(128, 1152).contiguous().cuda()
+            ws.append(wd)
+            lib.fr_conv_stage28_pack(_lib.ptr(wd), _lib.ptr(stream[(2 * k + j) * per:]), _lib.stream_ptr())
+        mid = F.conv2d(h, w1.float().permute(0, 3, 1, 2), None, 1, 1) + b9[rc][:, rc].permute(2, 0, 1)[None]
+        mid = torch.where(mid > 0, mid, mid * sl[None, :, None, None]).to(torch.float16).float()
+        h = (F.conv2d(mid, w2.float().permute(0, 3, 1, 2), None, 1, 1) + b2[None, :, None, None] + h).to(torch.float16).float()
+    xd, pd = x.cuda(), prm.cuda()
+    y = xd.clone()
+    scratch = torch.full_like(xd, float("nan"))
+    lib.fr_conv_stage28_f16(_lib.ptr(y), _lib.ptr(scratch), _lib.ptr(stream), _lib.ptr(pd), B, nblocks, _lib.stream_ptr())
+    torch.cuda.synchronize()
+    ref = h.permute(0, 2, 3, 1)
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err <= 3e-3 * ref.abs().max().item(), (err, ref.abs().max().item())
+    hh = xd
+    for k in range(nblocks):
+        m_ = torch.empty_like(xd); o_ = torch.empty_like(xd)
+        b9d, sld, b2d = pd[2 * k, :9].reshape(-1).contiguous(), pd[2 * k, 9].contiguous(), pd[2 * k + 1, 0].contiguous()
+        a = _lib.ConvArgs(_lib.ptr(hh), _lib.ptr(ws[2 * k]), _lib.ptr(m_), _lib.ptr(b9d), _lib.ptr(sld), None, None,
+                          B, 28, 28, 128, 128, 3, 3, 1, 1, 28, 28, 1, 1)
+        lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
+        a = _lib.ConvArgs(_lib.ptr(m_), _lib.ptr(ws[2 * k + 1]), _lib.ptr(o_), _lib.ptr(b2d), None, _lib.ptr(hh), None,
+                          B, 28, 28, 128, 128, 3, 3, 1, 1, 28, 28, 0, 1)
+        lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
+        hh = o_
+    torch.cuda.synchronize()
+    d = (y.float() - hh.float()).abs()
+    assert d.max().item() <= 2e-3 * ref.abs().max().item() and d.mean().item() < 1e-4 * ref.abs().max().item()
+
+
+def test_stage28_path_on_r100_equals_layer_path(r100):
+    """From 144 faces up the 12 stride-1 blocks of the 28x28 stage run as one launch: same embeddings as layer by layer to
+    f16 rounding noise (another f32 summation order)."""
+    g = torch.Generator().manual_seed(28)
+    xa = nchw_to_nhwc8(torch.rand((147, 3, 112, 112), generator=g) * 2 - 1)
+    assert r100.stage28 is not None and r100.stage28["n"] == 12
+    r100.profile = []
+    _, n1 = r100.forward(xa)
+    names = [p[0] for p in r100.profile]
+    r100.profile = None
+    assert names.count("conv_stage28_kernel") == 1
+    r100.use_stage28 = False
+    try:
+        _, n0 = r100.forward(xa)
+    finally:
+        r100.use_stage28 = True
+    torch.cuda.synchronize()
+    cos = (n0 * n1).sum(1)
+    assert (1 - cos).max().item() < 2e-5, (1 - cos).max().item()
+
+
 def test_stage14_path_on_r100_vs_golden_and_layer_path(r100, golden):
     """From 144 faces up the 29 stride-1 blocks of stage 3 run as ONE launch.  The two golden faces inside such a batch
     must meet north_star's bound against the fp32 oracle, and the whole batch must agree with the layer-by-layer path
