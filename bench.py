@@ -197,6 +197,8 @@ def main():
     ap.add_argument("--pipes", type=int, default=2, help="independent (detector, embedder) stream pairs, used round-robin")
     ap.add_argument("--prio", default="none", choices=["none", "det", "emb"], help="stream given high priority")
     ap.add_argument("--one-stream", action="store_true", help="detector and embedder on one stream (no overlap)")
+    ap.add_argument("--det-sides", type=int, default=None, help="A/B: side streams the detector deals pyramid levels 1.. over")
+    ap.add_argument("--det-level-nms", default=None, choices=["merged", "per-level"], help="A/B: per-level NMS as one launch or one per level")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--workload", default=None, choices=["C1", "C2", "C3", "C4", "C5"],
@@ -299,6 +301,11 @@ def main():
     # two HIP streams: the detector cascade of step i+1 (latency-bound) runs beside the embed convs of step i
     # (MFMA-bound); align/embed/match of a step wait for its own detector through an event
     two = not args.one_stream
+    app.det.one_stream = args.one_stream        # profiling: pyramid levels on one stream too, per-kernel durations add up
+    if args.det_sides is not None:
+        app.det.level_streams = args.det_sides
+    if args.det_level_nms is not None:
+        app.det.merged_level_nms = args.det_level_nms == "merged"
     pipes = []
     for _ in range(args.pipes if two else 1):
         pipes.append((torch.cuda.Stream(device=device, priority=-1 if args.prio == "det" else 0) if two else None,

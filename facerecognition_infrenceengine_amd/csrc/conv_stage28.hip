@@ -19,8 +19,9 @@
 //               one LDS-DMA piece per wave per step from ONE pre-swizzled stream for all convs (fr_conv_stage28_pack)
 //         prm   the conv's 9 border-class biases + PReLU slope, f32 [10][128]
 //   K     PLANE-major: 18 steps (9 taps x 2 channel groups) on plane 0, then 18 on plane 1 - so that plane 0's buffer is
-//         dead during the second half of a pass and the NEXT pass's plane 0 (the image's other half) is fetched under it;
-//         plane 1 follows under the epilogue.  Step as conv_stage14.hip: W(s+3) into step s's own slot, counted
+//         dead during the second half of a pass and the NEXT pass's plane 0 is fetched under it; plane 1 follows under the
+//         epilogue.  The next pass is the image's other half or, behind a conv's second half, the first half of the NEXT conv's
+//         input: 15 of its 16 halo rows were stored a pass ago, the last one follows behind this pass's store drain.  Step as conv_stage14.hip: W(s+3) into step s's own slot, counted
 //         vmcnt / lgkmcnt, weights double-buffered, pixel fragments re-read in place, the two waves of a SIMD issue
 //         their DMA pieces at opposite ends of a step, role-specialised copies of the unrolled loop.
 //   end   PReLU -> f16 straight from the accumulators (which started the pass as the pixel's border-class bias) to HBM (conv1 -> the scratch map `mid`, conv2 -> `x` in place);
@@ -145,6 +146,13 @@ __global__ __launch_bounds__(512, 2) void conv_stage28_kernel(Stage28P p) {
         const int fr = lane & 15, fq = lane >> 4;
         const bool second = conv & 1;
         __amdgpu_buffer_rsrc_t srs = second ? mrs : xrs;              // this conv's input map
+        // The NEXT pass's halo: the other half of the same input - or, behind a conv's second half, the first half of the map
+        // this conv writes: 15 of its 16 halo rows come from rows 0..13, stored (and drained) a pass ago; only halo row 15 =
+        // image row 14 belongs to the half being computed now and follows behind this pass's store drain.
+        __amdgpu_buffer_rsrc_t nxr = hf == 0 ? srs : (second ? xrs : mrs);
+        const int nxy0 = hf == 0 ? S28_TH : 0;
+        const bool nx_any = hf == 0 || conv + 1 < p.nconv;
+        auto nx_ok = [&](int i) { return nx_any && (hf == 0 || !(i == 7 && (wave >> 2) == 1)); };
         half_t* dst = second ? p.x : p.mid;
         const unsigned tile0 = (unsigned)((n * 28 + y0) * 28);        // first output pixel of the half (global pixel index)
         // weight fragment i = cout tile (i + wp) & 3 of the wave's 64 couts: a wave-uniform offset on ONE lane register
@@ -177,8 +185,10 @@ __global__ __launch_bounds__(512, 2) void conv_stage28_kernel(Stage28P p) {
         S28_STAMP(t0);
         // ---- accumulators start as their pixel's border-class bias (+ the residual: second conv of a block, this tile of x).
         // Here, not in the epilogue: 100 b128 LDS reads per wave are 6 k cycles of LDS time per pass, free while the halo is in flight.
-        if (hf == 0) {                                               // the conv's parameters were issued BEFORE its 16 halo pieces
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (hf == 0) {       // the conv's parameters were issued BEFORE the halo pieces still in flight (kernel start: 16; else waves 4..7: 2)
+            if (pass == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (wave >> 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
         auto cls_off = [&](int px) {
@@ -248,8 +258,8 @@ __global__ __launch_bounds__(512, 2) void conv_stage28_kernel(Stage28P p) {
                         int l_ = lane;
                         asm volatile("" : "+v"(l_));                 // the lane constant derived here, not kept (or spilled) across the loop
                         const unsigned ltp = halo_lane(l_);
-                        issue_halo(srs, 0, 2 * k, S28_TH, ltp, hf == 0);
-                        issue_halo(srs, 0, 2 * k + 1, S28_TH, ltp, hf == 0);
+                        issue_halo(nxr, 0, 2 * k, nxy0, ltp, nx_ok(2 * k));
+                        issue_halo(nxr, 0, 2 * k + 1, nxy0, ltp, nx_ok(2 * k + 1));
                     }
                 }
                 issue_w(k % 3, lane);
@@ -309,16 +319,13 @@ __global__ __launch_bounds__(512, 2) void conv_stage28_kernel(Stage28P p) {
         int le = lane;
         asm volatile("" : "+v"(le));
         const unsigned lt = halo_lane(le);
-        if (hf == 0)
-            for (int i = 0; i < 8; ++i) issue_halo(srs, 1, i, S28_TH, lt, true);
+        for (int i = 0; i < 8; ++i) issue_halo(nxr, 1, i, nxy0, lt, nx_ok(i));
         S28_PIN();
         const int fre = le & 15, fqe = le >> 4;
         auto coe = [&](int i) { return wn * 64 + ((i + wp) & 3) * 16 + fqe * 4; };
-        float4v sv[4];
-        if (!second) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sv[i] = *reinterpret_cast<const float4v*>(lprm + 9 * S28_C + coe(i));
-        }
+        float4v sv[4];                                               // read unconditionally: a conditional definition is carried through
+#pragma unroll                                                       // the pass loop (16 registers spilled across every K loop)
+        for (int i = 0; i < 4; ++i) sv[i] = *reinterpret_cast<const float4v*>(lprm + 9 * S28_C + coe(i));
         auto act = [&](float4v v, int i) {                           // the bias is in the accumulators since the pass start
             if (!second) {
 #pragma unroll
@@ -346,9 +353,11 @@ __global__ __launch_bounds__(512, 2) void conv_stage28_kernel(Stage28P p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (conv + 1 < p.nconv) {
-                issue_prm(conv + 1, lane);
-                __amdgpu_buffer_rsrc_t nrs = second ? xrs : mrs;
-                for (int i = 0; i < 16; ++i) issue_halo(nrs, i >> 3, i & 7, 0, lt, true);
+                issue_prm(conv + 1, lane);                           // first: the next pass waits for it with two pieces in flight
+                if (wave >> 2) {                                     // halo row 15 of both planes: this wave's piece 7
+                    issue_halo(nxr, 0, 7, 0, lt, true);
+                    issue_halo(nxr, 1, 7, 0, lt, true);
+                }
             }
             if (STAMPS) { unsigned long long t5; S28_STAMP(t5); s_drain += t5 - t4; }
         }

@@ -209,7 +209,7 @@ class FaceAnalysis:
             kps = kps.contiguous()
         else:
             with torch.cuda.stream(det_stream):
-                boxes, scores, kps, counts = self.det.detect_batch(frames, level_streams=1)     # overlapped with the embedder
+                boxes, scores, kps, counts = self.det.detect_batch(frames)     # overlapped with the embedder
                 kps = kps.contiguous()
             cur.wait_stream(det_stream)
             for t in (boxes, scores, kps, counts):

@@ -6,7 +6,6 @@ counts, so a whole batch of frames runs without a host synchronisation.  Convent
 ordering, thresholds, capacities) are those written down in ``oracle/detect.py``.
 """
 import math
-import os
 import threading
 
 import torch
@@ -131,8 +130,8 @@ class MTCNNHIP:
         assert cap_scale <= 4096 and cap_p <= 1024 and cap_r <= 1024 and cap_o <= 1024
         self._sides = {}
         self._tls = threading.local()      # per-thread launch stream: detect_batch is re-entrant across threads
-        self._one_stream = os.environ.get("FR_DET_ONE_STREAM") == "1"      # profiling: per-kernel times add up
-        self._nsides = int(os.environ.get("FR_DET_SIDES", "1"))
+        self.one_stream = False            # True (profiling): every pyramid level on the caller's stream, per-kernel times add up
+        self.level_streams = 1             # side streams the pyramid levels 1.. are dealt over (detect_batch's default)
         self.phase_marks = None            # tools: a list -> (name, event on the caller's stream) at the cascade's phase ends
         self.merged_level_nms = False      # True: the per-level NMS of ALL levels as one launch behind the pyramid
         d = self.device
@@ -327,12 +326,12 @@ class MTCNNHIP:
             sides = self._sides.get(main.cuda_stream)         # side streams per caller stream: independent
             if sides is None:                                 # pipelines (bench --pipes) do not couple through them
                 sides = self._sides[main.cuda_stream] = [torch.cuda.Stream(device=self.device) for _ in range(2)]
-            sides = sides[:max(1, min(2, level_streams if level_streams is not None else self._nsides))]
+            sides = sides[:max(1, min(2, level_streams if level_streams is not None else self.level_streams))]
             for side in sides:
                 side.wait_stream(main)
             for li, s in enumerate(scales):
                 side = sides[(li - 1) % len(sides)] if li else sides[0]
-                with torch.cuda.stream(main if li == 0 or trace is not None or self._one_stream else side):
+                with torch.cuda.stream(main if li == 0 or trace is not None or self.one_stream else side):
                     self._s = _lib.stream_ptr()
                     head, hc, wc = self.pnet_level(frames, s, trace)
                     nblk = -(-hc * wc // 256)

@@ -66,9 +66,9 @@ print("stage alone on a CU subset (ms per 64 x 1080p frames / per 256 faces):", 
 for n8 in (8, 6, 5, 4, 3, 2):
     s = masked_stream(subset(n8))
     app.rec.use_stage14 = n8 == 8                      # the one-image-per-CU stage kernel needs all 256 CUs for 256 faces
-    os.environ['FR_DET_ONE_STREAM'] = '1'; app.det._one_stream = True          # every level on the masked stream
+    app.det.one_stream = True          # every level on the masked stream
     d = timed(lambda: app.det.detect_batch(batches[0], level_streams=1), s)
-    app.det._one_stream = False
+    app.det.one_stream = False
     e = timed(lambda: app.rec.forward(crops), s)
     print(f"  {n8 * 32:3d} CUs: detect {d:6.2f}  embed {e:6.2f}" + ("  (stage kernel)" if n8 == 8 else "  (layer by layer)"), flush=True)
 

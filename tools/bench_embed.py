@@ -11,7 +11,7 @@ MODES = sys.argv[2].split(",") if len(sys.argv) > 2 else ["f16", "fp8"]
 for mode in MODES:
     if mode == "fp8":
         net.enable_fp8(x[:32].contiguous())
-    net.use_rows28 = mode != "f16_halo28"          # A/B: 28x28 convs on the general halo kernel
+    net.use_stage28 = mode != "f16_layers28"       # A/B: the 28x28 run layer by layer
     for _ in range(3): net.forward(x)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/prof3
 cd $R
 # 1. single-stream kernel stats of the bench
-FR_DET_ONE_STREAM=1 timeout -k 10 400 rocprofv3 --output-format csv --kernel-trace --stats -d $R/gpurun_out/prof3/stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-side --one-stream > $R/gpurun_out/prof3/bench_single_stream.json 2> $R/gpurun_out/prof3/bench_single_stream.err
+timeout -k 10 400 rocprofv3 --output-format csv --kernel-trace --stats -d $R/gpurun_out/prof3/stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-side --one-stream > $R/gpurun_out/prof3/bench_single_stream.json 2> $R/gpurun_out/prof3/bench_single_stream.err
 # 2. HBM traffic passes over the embed net
 timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/prof3/fetch -- python3 tools/bench_embed.py 256 f16 > $R/gpurun_out/prof3/fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/prof3/write -- python3 tools/bench_embed.py 256 f16 > $R/gpurun_out/prof3/write.log 2>&1
