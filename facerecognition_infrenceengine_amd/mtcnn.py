@@ -133,7 +133,7 @@ class MTCNNHIP:
         self.one_stream = False            # True (profiling): every pyramid level on the caller's stream, per-kernel times add up
         self.level_streams = 1             # side streams the pyramid levels 1.. are dealt over (detect_batch's default)
         self.phase_marks = None            # tools: a list -> (name, event on the caller's stream) at the cascade's phase ends
-        self.merged_level_nms = False      # True: the per-level NMS of ALL levels as one launch behind the pyramid
+        self.merged_level_nms = True       # the per-level NMS of ALL levels as one launch behind the pyramid (False: one per level)
         d = self.device
         p, r, o = ({k: v.detach().float().cpu() for k, v in s.items()} for s in (pstate, rstate, ostate))
         self.p1 = _MConv(0, p["conv1.weight"], p["conv1.bias"], p["prelu1.weight"], d)
@@ -296,9 +296,12 @@ class MTCNNHIP:
         """frames: uint8 [N,H,W,3] BGR device tensor (contiguous).
 
         level_streams: side HIP streams (1 or 2) the pyramid levels 1.. are dealt over; level 0 stays on the caller's
-        stream.  Default 1.  Two were measured: a 64 x 1080p batch ALONE in a fresh process 7.55 -> 7.1 ms (three: the
-        same, four: slower), but nothing inside the bench process (7.9 either way with its dozen other streams) and
-        ~1 % less end-to-end throughput when the detector is overlapped with the embedder - so it stays an option.
+        stream.  Default ``self.level_streams`` = 1.  Measured (round 3): a 64 x 1080p batch ALONE (tools/bench_det_phases.py):
+        one side stream + an NMS launch per level 6.80 ms, two side streams 6.47, one launch for the NMS of all levels
+        (``merged_level_nms``, the default: 768 one-workgroup sorts at once instead of twelve launches of 64) 6.54 / 6.37 ms.
+        Inside the bench, where the detector shares the GPU with the embedder: 64 x 1080p the four combinations are within
+        the run-to-run noise (12.3 - 12.7 ms/step); 8 x 4K frames (config C3) 6.10 ms/step with one side stream + merged NMS,
+        6.30 with the per-level launches, 6.6 - 6.9 with two side streams - hence the defaults.
 
         Returns device tensors: boxes f32 [N,cap_o,4], scores f32 [N,cap_o], kps f32 [N,cap_o,5,2],
         counts i32 [N] (faces per frame, in descending-score order)."""
@@ -341,9 +344,8 @@ class MTCNNHIP:
                     lib.fr_pnet_candidates(_lib.ptr(head), N, hc, wc, float(s), t0, cs, _lib.ptr(lb[li]), _lib.ptr(ls[li]),
                                            _lib.ptr(lr[li]), _lib.ptr(lc[li]), _lib.ptr(bc), _lib.ptr(prob), _lib.ptr(dl),
                                            dl_min, self._s)
-                    # per-level NMS 0.5 -> keep_scale survivors.  Batches: right behind the level's own kernels on the
-                    # level's stream, so the one-workgroup-per-list sorts (latency-bound) run under the other levels'
-                    # P-Net.  Single frames are launch-bound: one launch for all levels after the loop instead.
+                    # per-level NMS 0.5 -> keep_scale survivors: one launch for all levels behind the loop (default), or
+                    # right behind the level's own kernels on the level's stream (merged_level_nms False, batches only)
                     if N >= 8 and not self.merged_level_nms:
                         self._nms(lb[li], ls[li], lr[li], 4, lc[li], N, 1, cs, 0, 0.5, 0, ksz, out=(kb[li], ks[li], ka[li], kc[li]))
                     if trace is not None:

@@ -27,3 +27,10 @@ for mode in MODES:
     net.profile = None
     for v, (n, fl, t) in sorted(per.items(), key=lambda kv: -kv[1][2]):
         print(f"   {v:62s} x{n:3d} {t:7.3f} ms  {fl/t/1e9:7.0f} TFLOP/s")
+    if len(sys.argv) > 3 and sys.argv[3] == "detail":          # every launch in network order
+        net.profile = []
+        net.forward(x); torch.cuda.synchronize()
+        for v, fl, a, b in net.profile:
+            t = a.elapsed_time(b)
+            print(f"      {v[:58]:58s} {t * 1e3:8.1f} us {fl / 1e9:8.1f} GFLOP {fl / t / 1e9:7.0f} TFLOP/s")
+        net.profile = None

@@ -14,6 +14,8 @@ timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_MF
 python3 tools/pmc_traffic.py $R/gpurun_out/prof3/fetch $R/gpurun_out/prof3/write $R/gpurun_out/prof3/r03_pmc_traffic.json > $R/gpurun_out/prof3/pmc_traffic.txt 2>&1
 python3 tools/pmc_sum.py $R/gpurun_out/prof3/sqa conv_stage14 > $R/gpurun_out/prof3/sq_counters.txt 2>&1
 python3 tools/pmc_sum.py $R/gpurun_out/prof3/sqb conv_stage14 >> $R/gpurun_out/prof3/sq_counters.txt 2>&1
+python3 tools/pmc_sum.py $R/gpurun_out/prof3/sqa conv_stage28 > $R/gpurun_out/prof3/sq_counters_stage28.txt 2>&1
+python3 tools/pmc_sum.py $R/gpurun_out/prof3/sqb conv_stage28 >> $R/gpurun_out/prof3/sq_counters_stage28.txt 2>&1
 find $R/gpurun_out/prof3 -name "*kernel_stats.csv" | head
 # keep only small files
 find $R/gpurun_out/prof3 -name "*.csv" -size +2000k -delete
