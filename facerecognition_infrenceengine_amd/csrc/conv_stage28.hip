@@ -1,4 +1,4 @@
-// The run of stride-1 residual blocks of IResNet's 28x28 x 128 stage (r100: 12 blocks = 24 convs, 14 % of the network's
+// The run of stride-1 residual blocks of IResNet's 28x28 x 128 stage (r100: 12 blocks = 24 convs, 23 % of the network's
 // FLOPs; the embed half of `FaceAnalysis.get`, /root/reference/infrenceServer.py:528) as ONE launch, one workgroup per FACE.
 //
 // A 28x28x128 f16 map is 200 KB: unlike the 14x14 stage (conv_stage14.hip) it cannot stay in LDS.  Launched layer by layer
