@@ -21,7 +21,8 @@ class ConvArgs(C.Structure):
                 ("out_f32_partial", C.c_void_p),
                 ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
                 ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
-                ("Ho", C.c_int), ("Wo", C.c_int), ("bias_mode", C.c_int), ("splitk", C.c_int)]
+                ("Ho", C.c_int), ("Wo", C.c_int), ("bias_mode", C.c_int), ("splitk", C.c_int),
+                ("x2", C.c_void_p), ("C2", C.c_int)]
 
 
 class ConvStep(C.Structure):

@@ -604,7 +604,7 @@ static int launch_halo(const HaloP& p, hipStream_t s) {
 
 // Returns 1 if the halo kernel handled the layer, 0 if the shape is not eligible, < 0 on error.
 int fr_conv_halo_try(const fr_conv_args* a, hipStream_t s) {
-    if (!(a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->H == a->W && a->out_f32_partial == nullptr))
+    if (!(a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->H == a->W && a->out_f32_partial == nullptr) || a->x2)
         return 0;
     if (a->Cin % 64 != 0 || a->Cout % 64 != 0) return 0;
     int TH, G = 1;

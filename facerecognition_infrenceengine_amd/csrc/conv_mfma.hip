@@ -24,6 +24,7 @@ struct ConvP {
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, bias_mode, splitk;
     int M, K, nk;            // M = B*Ho*Wo, K = row length of w (halves), nk = K / 64
     unsigned xbytes, wbytes;
+    const half_t* x2; int C2, nk_main; unsigned x2bytes;      // second input through a 1x1 tap (fr_conv_args.x2): K steps nk_main .. nk-1
 };
 
 __device__ __forceinline__ int4v buf_load16(__amdgpu_buffer_rsrc_t rs, unsigned off) {
@@ -127,6 +128,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
     unsigned wbase[WROWS];
 #pragma unroll
     for (int i = 0; i < WROWS; ++i) wbase[i] = ((unsigned)(cout0 + wrow(i)) * p.K + tchunk * 8) * 2;
+    // second input (1x1 tap at the output pixel's stride position): same pixel raster, its own channel count
+    __amdgpu_buffer_rsrc_t x2rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x), 0, p.x2 ? p.x2bytes : 0u, 0x00020000);
+    auto x2off = [&](int i, int c0) -> unsigned {
+        if (xhw[i] == (int)0x80000000u) return 0x80000000u;
+        const int bh = (xhw[i] >> 16) + p.pad, bw = (int)(short)(xhw[i] & 0xffff) + p.pad;      // = ho * stride, wo * stride
+        const int n = (m0 + xrow(i)) / HoWo;
+        return (unsigned)((((n * p.H + bh) * p.W + bw) * p.C2 + c0 + tchunk * 8) * 2);
+    };
 
     // K range of this block (split-K over blockIdx.z)
     int ks = 0, ke = p.nk;
@@ -157,6 +166,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
         for (int i = 0; i < WROWS; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(wl + (wave * WROWS + i) * 8 * BK), 16,
                                                      wbase[i] + (unsigned)s * (BK * 2), 0, 0, 0);
+        if (!SMALL_CIN && s >= p.nk_main) {                          // block-uniform: the second input's K steps
+#pragma unroll
+            for (int i = 0; i < XROWS; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x2rs, (lds_ptr_t)(xl + (wave * XROWS + i) * 8 * BK), 16,
+                                                         x2off(i, (s - p.nk_main) * BK), 0, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < XROWS; ++i) {
             int hi = (xhw[i] >> 16) + kh, wi = (int)(short)(xhw[i] & 0xffff) + kw;
@@ -179,6 +195,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
         }
 #pragma unroll
         for (int i = 0; i < WROWS; ++i) wreg[i] = buf_load16(wrs, wbase[i] + (unsigned)s * (BK * 2));
+        if (!SMALL_CIN && s >= p.nk_main) {
+#pragma unroll
+            for (int i = 0; i < XROWS; ++i) xreg[i] = buf_load16(x2rs, x2off(i, (s - p.nk_main) * BK));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < XROWS; ++i) {
             int hi = (xhw[i] >> 16) + kh, wi = (int)(short)(xhw[i] & 0xffff) + kw;
@@ -391,8 +412,8 @@ template <int WN, bool SMALL>
 static void launch_conv(const ConvP& p, hipStream_t s) {
     constexpr int BN = 64 * WN, BM = 64 * (4 / WN);
     dim3 grid((p.M + BM - 1) / BM, p.Cout / BN, p.splitk > 1 ? p.splitk : 1);
-    if constexpr (FR_DEBUG) {                  // measured alternatives, debug build only
-        const int which = conv_kernel_choice();
+    if constexpr (FR_DEBUG) {                  // measured alternatives, debug build only (none of them takes a second input)
+        const int which = p.x2 ? 1 : conv_kernel_choice();
         if (which == 2) {
             ConvP q = p;
             q.nk = p.K / PK;
@@ -434,7 +455,14 @@ extern "C" int fr_conv_nhwc_f16(const fr_conv_args* a, fr_stream_t stream) {
     int64_t M = (int64_t)a->B * a->Ho * a->Wo;
     int64_t xbytes = (int64_t)a->B * a->H * a->W * a->Cin * 2;
     int Kreal = a->KH * a->KW * a->Cin;
-    p.K = small ? ((Kreal + 127) / 128) * 128 : Kreal;
+    FR_REQUIRE(!a->x2 || (!small && a->C2 > 0 && a->C2 % 64 == 0 && (a->H - 1) / a->stride + 1 >= a->Ho && (a->W - 1) / a->stride + 1 >= a->Wo),
+               "fr_conv_nhwc_f16: x2 needs Cin %% 64 == 0, C2 %% 64 == 0 and every (ho * stride, wo * stride) inside the image");
+    p.x2 = (const half_t*)a->x2; p.C2 = a->x2 ? a->C2 : 0;
+    p.K = small ? ((Kreal + 127) / 128) * 128 : Kreal + p.C2;
+    p.nk_main = Kreal / BK;
+    int64_t x2bytes = (int64_t)a->B * a->H * a->W * p.C2 * 2;
+    FR_REQUIRE(x2bytes < (1ll << 31), "fr_conv_nhwc_f16: x2 too large for 32-bit buffer offsets");
+    p.x2bytes = (unsigned)x2bytes;
     int64_t wbytes = (int64_t)a->Cout * p.K * 2;
     FR_REQUIRE(M < (1ll << 31) && xbytes < (1ll << 31) && wbytes < (1ll << 31) && M * a->Cout * 2 < (1ll << 40),
                "fr_conv_nhwc_f16: tensor too large for 32-bit buffer offsets (split the batch)");

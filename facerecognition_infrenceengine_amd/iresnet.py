@@ -173,7 +173,7 @@ def fold_iresnet(state, arch="r100"):
 
 class _Conv:
     __slots__ = ("w", "bias", "slope", "cin", "cout", "k", "stride", "pad", "bias_mode", "w32", "w8", "sw", "sx",
-                 "oscale", "mu", "bias8")
+                 "oscale", "mu", "bias8", "c2")
 
     def __init__(self, w, bias, slope, cin, cout, k, stride, pad, bias_mode, device):
         self.w = w.to(device)
@@ -181,6 +181,7 @@ class _Conv:
         self.bias = None if bias is None else bias.to(torch.float32).contiguous().to(device)
         self.slope = None if slope is None else slope.to(torch.float32).contiguous().to(device)
         self.cin, self.cout, self.k, self.stride, self.pad, self.bias_mode = cin, cout, k, stride, pad, bias_mode
+        self.c2 = 0                  # channels of a second input that enters through a 1x1 tap (fr_conv_args.x2): fused shortcut
 
 
 class IResNetHIP:
@@ -214,6 +215,16 @@ class IResNetHIP:
             if ds is not None:
                 sc = _Conv(_pack_w(ds["w"]), ds["bias"], None, ds["cin"], ds["cout"], 1, ds["stride"], 0, 0, dev)
             self.blocks.append((c1, c2, sc))
+        # A stage-entry block's 1x1 / stride-2 shortcut conv joins its stride-2 3x3 conv as extra K rows of ONE implicit GEMM
+        # (f32 accumulation, biases summed): no shortcut launch, no f16 shortcut map written and read back.
+        self.fused_sc = {}
+        self.fuse_shortcut = True    # False: shortcut conv as its own launch (A/B, tests)
+        for i, (c1, c2, sc) in enumerate(self.blocks):
+            if sc is not None and sc.k == 1 and sc.stride == c2.stride and sc.cin % 64 == 0 and c2.cin % 64 == 0:
+                fz = _Conv(torch.cat([c2.w.reshape(c2.cout, -1), sc.w.reshape(sc.cout, -1)], 1).contiguous(),
+                           c2.bias + sc.bias, None, c2.cin, c2.cout, 3, c2.stride, 1, 0, dev)
+                fz.c2 = sc.cin
+                self.fused_sc[i] = fz
         self._pack_stage14()
         self._pack_stage28()
         self.fc_w = f["fc_w"].to(torch.float16).contiguous().to(dev)
@@ -514,7 +525,7 @@ class IResNetHIP:
             return -(-nk // 3)
         return min(8, nk // 9)
 
-    def _conv(self, x, c, B, H, W, residual=None, partial=None, splitk=1, y=None):
+    def _conv(self, x, c, B, H, W, residual=None, partial=None, splitk=1, y=None, x2=None):
         Ho = (H + 2 * c.pad - c.k) // c.stride + 1
         Wo = (W + 2 * c.pad - c.k) // c.stride + 1
         sk = self._small_batch_splitk(c, B) if partial is None and self.profile is None else 1
@@ -524,7 +535,7 @@ class IResNetHIP:
             M = B * Ho * Wo
             part = torch.empty((sk, M, c.cout), dtype=torch.float32, device=self.device)
             a = _lib.ConvArgs(_lib.ptr(x), _lib.ptr(c.w), None, None, None, None, _lib.ptr(part),
-                              B, H, W, c.cin, c.cout, c.k, c.k, c.stride, c.pad, Ho, Wo, 0, sk)
+                              B, H, W, c.cin, c.cout, c.k, c.k, c.stride, c.pad, Ho, Wo, 0, sk, _lib.ptr(x2), getattr(c, "c2", 0))
             self.lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
             self.lib.fr_conv_splitk_epilogue(_lib.ptr(part), sk, M, c.cout, Ho, Wo, _lib.ptr(c.bias), c.bias_mode,
                                              _lib.ptr(c.slope), _lib.ptr(residual), _lib.ptr(y), _lib.stream_ptr())
@@ -533,7 +544,8 @@ class IResNetHIP:
             y = torch.empty((B, Ho, Wo, c.cout), dtype=torch.float16, device=self.device)
         a = _lib.ConvArgs(_lib.ptr(x), _lib.ptr(c.w) if isinstance(c, _Conv) else None, _lib.ptr(y),
                           _lib.ptr(c.bias), _lib.ptr(c.slope), _lib.ptr(residual), _lib.ptr(partial),
-                          B, H, W, c.cin, c.cout, c.k, c.k, c.stride, c.pad, Ho, Wo, c.bias_mode, splitk)
+                          B, H, W, c.cin, c.cout, c.k, c.k, c.stride, c.pad, Ho, Wo, c.bias_mode, splitk,
+                          _lib.ptr(x2), getattr(c, "c2", 0) if x2 is not None else 0)
         if self.profile is not None:
             # HIP events on the stream the kernel is launched on (torch's current stream)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -551,7 +563,7 @@ class IResNetHIP:
                     halo = "conv_halo_kernel<1, 14, 512, 1, 4, false, false, 4, false, 8, 0>"
             variant = halo or ("conv_stem_kernel<112>" if c.cin == 8 else
                                "conv_mfma_kernel<%d, false, true>" % (2 if c.cout % 128 == 0 else 1))
-            kreal = 27 if c.cin == 8 else c.k * c.k * c.cin       # algorithmic K (stem: 3 real channels)
+            kreal = 27 if c.cin == 8 else c.k * c.k * c.cin + (getattr(c, "c2", 0) if x2 is not None else 0)   # algorithmic K (stem: 3 real channels)
             self.profile.append((variant, 2.0 * B * Ho * Wo * c.cout * kreal, e0, e1))
         else:
             self.lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
@@ -620,40 +632,44 @@ class IResNetHIP:
         def view(buf, Ho, Wo, c):
             return buf[:B * Ho * Wo * c].view(B, Ho, Wo, c)
 
-        def add(c, x, y, H, W, residual=None):
+        def add(c, x, y, H, W, residual=None, x2=None):
             nonlocal part_floats
             Ho = (H + 2 * c.pad - c.k) // c.stride + 1
             Wo = (W + 2 * c.pad - c.k) // c.stride + 1
             sk = self._small_batch_splitk(c, B)
             if sk > 1:
                 part_floats = max(part_floats, sk * B * Ho * Wo * c.cout)
-            steps.append((1 if sk > 1 else 0, c, x, y, residual, H, W, Ho, Wo, sk))
+            steps.append((1 if sk > 1 else 0, c, x, y, residual, H, W, Ho, Wo, sk, x2))
             return Ho, Wo
 
         free = list(bufs)
         h = free.pop()
         H, W = add(self.stem, None, h, 112, 112)                      # x (the crops) is patched in per call
         hc = 64
-        for c1, c2, sc in self.blocks:
+        for bi_, (c1, c2, sc) in enumerate(self.blocks):
             mid = free.pop()
             add(c1, view(h, H, W, hc), mid, H, W)
             short = view(h, H, W, hc)
             s_buf = None
-            if sc is not None:
+            fz = self.fused_sc.get(bi_) if self.fuse_shortcut else None
+            if sc is not None and fz is None:
                 s_buf = free.pop()
                 Ho, Wo = add(sc, view(h, H, W, hc), s_buf, H, W)
                 short = view(s_buf, Ho, Wo, sc.cout)
             out = free.pop()
-            Ho, Wo = add(c2, view(mid, H, W, c1.cout), out, H, W, residual=short)
+            if fz is not None:
+                Ho, Wo = add(fz, view(mid, H, W, c1.cout), out, H, W, x2=short)
+            else:
+                Ho, Wo = add(c2, view(mid, H, W, c1.cout), out, H, W, residual=short)
             free += [b for b in (h, mid, s_buf) if b is not None]
             h, H, W, hc = out, Ho, Wo, c2.cout
         assert part_floats <= partial.numel()
         arr = (_lib.ConvStep * len(steps))()
-        for st, (kind, c, x, y, residual, Hi, Wi, Ho, Wo, sk) in zip(arr, steps):
+        for st, (kind, c, x, y, residual, Hi, Wi, Ho, Wo, sk, x2) in zip(arr, steps):
             st.kind = kind
             st.args = _lib.ConvArgs(_lib.ptr(x), _lib.ptr(c.w), _lib.ptr(y), _lib.ptr(c.bias), _lib.ptr(c.slope),
                                     _lib.ptr(residual), _lib.ptr(partial) if kind else None, B, Hi, Wi, c.cin, c.cout,
-                                    c.k, c.k, c.stride, c.pad, Ho, Wo, c.bias_mode, sk)
+                                    c.k, c.k, c.stride, c.pad, Ho, Wo, c.bias_mode, sk, _lib.ptr(x2), c.c2 if x2 is not None else 0)
         plan = self._plans[key] = (arr, len(steps), view(h, H, W, hc), bufs, partial)
         return plan
 
@@ -711,15 +727,19 @@ class IResNetHIP:
                 mid, mid8 = self._conv_f8(h8, c1, B, H, W, want16=not f2 or taps is not None, nxt=c2 if f2 else None)
             else:
                 mid, _, _ = self._conv(h, c1, B, H, W)
+            fz = self.fused_sc.get(bi_) if self.fuse_shortcut and not f2 else None
             if sc is not None:
                 li += 1
                 if taps is not None:
                     taps[f"layer{li}.0.mid"] = mid
-                short, _, _ = self._conv(h, sc, B, H, W)
+                short = None if fz is not None else self._conv(h, sc, B, H, W)[0]
             else:
                 short = h
             self._calib_observe(c2, mid, H)
-            if f2:
+            if fz is not None:                         # stride-2 conv + 1x1 shortcut of the block input as one implicit GEMM
+                h, H, W = self._conv(mid, fz, B, H, W, x2=h)
+                h8 = None
+            elif f2:
                 if mid8 is None:
                     mid8 = self._quantise(mid, c2)
                 nxt = self.blocks[bi_ + 1][0] if bi_ + 1 < nb else None

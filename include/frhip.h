@@ -139,13 +139,18 @@ int fr_mean_rows_f32(const float* x, int K, int D, float* out, fr_stream_t strea
  * pre-activation BN shift through the zero padding; 3x3/s1/p1 only), or NULL.
  * slope: f32 [Cout] PReLU slopes or NULL.  residual: f16 [M,Cout] or NULL.
  * out_f32_partial != NULL: split-K mode, raw f32 partial sums [splitk][M][Cout]
- * (no epilogue), used for the FC 25088->512 (H=W=1, Cin=25088). */
+ * (no epilogue), used for the FC 25088->512 (H=W=1, Cin=25088).
+ * x2 != NULL: a second input [B,H,W,C2] f16 (same H, W as x; C2 % 64 == 0) that enters through a 1x1 tap at
+ * (ho * stride, wo * stride) as C2 extra K rows - w is then [Cout][KH*KW*Cin + C2].  An IResNet stage-entry block's
+ * 1x1 / stride-2 shortcut conv of the block input, summed with its stride-2 3x3 conv in ONE implicit GEMM (f32
+ * accumulation; biases summed by the caller) instead of a launch, an f16 map written and read back. */
 typedef struct {
     const void* x; const void* w; void* y;
     const float* bias; const float* slope; const void* residual;
     float* out_f32_partial;
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
     int bias_mode; int splitk;
+    const void* x2; int C2;
 } fr_conv_args;
 int fr_conv_nhwc_f16(const fr_conv_args* args, fr_stream_t stream);
 /* fp8 form of the body convs (BASELINE config C5: "fp8 ArcFace conv path, CDNA4 fp8 MFMA"; same reference site,

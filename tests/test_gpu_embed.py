@@ -78,6 +78,74 @@ def test_conv_layer_vs_torch(lib, case):
     _conv_case(lib, *case, seed=hash(case) & 0xffff)
 
 
+@pytest.mark.parametrize("B,H,Cmid,C2,Cout,splitk", [(2, 28, 128, 64, 128, 1), (3, 56, 64, 64, 64, 1), (1, 14, 256, 128, 256, 1),
+                                                      (1, 14, 512, 256, 512, 4), (2, 13, 64, 64, 128, 1)])
+def test_conv_with_second_input_vs_torch(lib, B, H, Cmid, C2, Cout, splitk):
+    """fr_conv_args.x2: a stage-entry block's stride-2 3x3 conv and the 1x1 / stride-2 shortcut conv of the block input as ONE
+    implicit GEMM (w = [3x3 rows | 1x1 rows]) against torch fp32 conv + conv on the same f16 operands; odd image size (the 1x1
+    tap's last position is the last pixel), 64- and 128-cout tiles, and the split-K form + fr_conv_splitk_epilogue."""
+    from facerecognition_infrenceengine_amd import _lib
+    g = torch.Generator().manual_seed(H * 1000 + Cmid + C2)
+    mid = torch.randn((B, Cmid, H, H), generator=g).to(torch.float16)
+    x = torch.randn((B, C2, H, H), generator=g).to(torch.float16)
+    w3 = (torch.randn((Cout, Cmid, 3, 3), generator=g) * (1.0 / (9 * Cmid)) ** 0.5).to(torch.float16)
+    w1 = (torch.randn((Cout, C2, 1, 1), generator=g) * (1.0 / C2) ** 0.5).to(torch.float16)
+    bias = torch.randn(Cout, generator=g)
+    ref = F.conv2d(mid.float(), w3.float(), None, 2, 1) + F.conv2d(x.float(), w1.float(), None, 2, 0) + bias[None, :, None, None]
+    Ho = (H + 2 - 3) // 2 + 1
+    assert ref.shape[2] == Ho
+    md = mid.permute(0, 2, 3, 1).contiguous().cuda()
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wd = torch.cat([w3.permute(0, 2, 3, 1).reshape(Cout, -1), w1.reshape(Cout, C2)], 1).contiguous().cuda()
+    bd = bias.cuda()
+    y = torch.full((B, Ho, Ho, Cout), float("nan"), dtype=torch.float16, device="cuda")
+    if splitk == 1:
+        a = _lib.ConvArgs(_lib.ptr(md), _lib.ptr(wd), _lib.ptr(y), _lib.ptr(bd), None, None, None,
+                          B, H, H, Cmid, Cout, 3, 3, 2, 1, Ho, Ho, 0, 1, _lib.ptr(xd), C2)
+        lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
+    else:
+        part = torch.empty((splitk, B * Ho * Ho, Cout), dtype=torch.float32, device="cuda")
+        st = (_lib.ConvStep * 1)()
+        st[0].kind = 1
+        st[0].args = _lib.ConvArgs(_lib.ptr(md), _lib.ptr(wd), _lib.ptr(y), _lib.ptr(bd), None, None, _lib.ptr(part),
+                                   B, H, H, Cmid, Cout, 3, 3, 2, 1, Ho, Ho, 0, splitk, _lib.ptr(xd), C2)
+        lib.fr_conv_sequence(st, 1, _lib.stream_ptr())
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 2e-3 * scale + 2e-3, (err, scale)
+
+
+def test_conv_second_input_is_refused_where_it_cannot_be_honoured(lib):
+    """x2 with the packed stem (Cin == 8) or a channel count that is not a multiple of 64: an error, not a silent drop."""
+    from facerecognition_infrenceengine_amd import _lib
+    t = torch.zeros(1 << 16, dtype=torch.float16, device="cuda")
+    a = _lib.ConvArgs(_lib.ptr(t), _lib.ptr(t), _lib.ptr(t), None, None, None, None, 1, 8, 8, 64, 64, 3, 3, 2, 1, 4, 4, 0, 1, _lib.ptr(t), 32)
+    with pytest.raises(_lib.FrError):
+        lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
+
+
+def test_fused_shortcut_path_on_r100_equals_separate_shortcut_convs(r100):
+    """The four stage-entry blocks run their shortcut inside the stride-2 conv: same embeddings as with the shortcut as its own
+    launch, to f16 rounding noise (the shortcut map is no longer rounded to f16 before it is added), batch and single-frame path."""
+    g = torch.Generator().manual_seed(31)
+    assert sorted(r100.fused_sc) == [0, 3, 16, 46]
+    for nfaces in (5, 150):
+        xa = nchw_to_nhwc8(torch.rand((nfaces, 3, 112, 112), generator=g) * 2 - 1)
+        r100.release_plans()
+        _, n1 = r100.forward(xa)
+        r100.fuse_shortcut = False
+        r100.release_plans()
+        try:
+            _, n0 = r100.forward(xa)
+        finally:
+            r100.fuse_shortcut = True
+            r100.release_plans()
+        torch.cuda.synchronize()
+        assert (1 - (n0 * n1).sum(1)).max().item() < 2e-5
+
+
 @pytest.mark.parametrize("B,H,W", [(3, 112, 112), (1, 8, 16), (2, 20, 48)])
 def test_stem_kernel_vs_torch(lib, B, H, W):
     """The packed stem (f16 [B,H,W,8]: RGB + zeros; weights [64][16 taps][8]) has its own kernel (conv_stem.hip): against
