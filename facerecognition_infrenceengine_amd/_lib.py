@@ -71,6 +71,9 @@ SIGNATURES = {
     "fr_conv_stage14_weight_bytes": (_Z, [_I]),
     "fr_conv_stage14_pack": (_I, [_P, _P, _P]),
     "fr_conv_stage14_f16": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "fr_conv_walk64_weight_bytes": (_Z, [_I]),
+    "fr_conv_walk64_pack": (_I, [_P, _P, _I, _P]),
+    "fr_conv_walk64_f16": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
     "fr_conv_stage28_weight_bytes": (_Z, [_I]),
     "fr_conv_stage28_pack": (_I, [_P, _P, _P]),
     "fr_conv_stage28_f16": (_I, [_P, _P, _P, _P, _I, _I, _P]),

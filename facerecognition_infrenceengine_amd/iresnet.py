@@ -37,6 +37,7 @@ MAX_PLAN_STREAMS = 8
 # (fr_conv_stage14_f16: one workgroup per image, one image per CU); below, the per-layer path fills the CUs better
 # (measured r100 forward, stage / layer by layer: 128 faces 4.62 / 4.44 ms, 160: 5.16 / 5.74, 192: 5.49 / 6.17, 256: 6.8 / 7.6)
 STAGE14_MIN_BATCH = 144
+WALK64_MIN_BATCH = 144      # fr_conv_walk64_f16: one workgroup per (face, 64-cout group)
 STAGE28_MIN_BATCH = 144     # fr_conv_stage28_f16: one workgroup per face, as the 14x14 stage kernel
 
 
@@ -173,7 +174,7 @@ def fold_iresnet(state, arch="r100"):
 
 class _Conv:
     __slots__ = ("w", "bias", "slope", "cin", "cout", "k", "stride", "pad", "bias_mode", "w32", "w8", "sw", "sx",
-                 "oscale", "mu", "bias8", "c2")
+                 "oscale", "mu", "bias8", "c2", "w64")
 
     def __init__(self, w, bias, slope, cin, cout, k, stride, pad, bias_mode, device):
         self.w = w.to(device)
@@ -181,6 +182,7 @@ class _Conv:
         self.bias = None if bias is None else bias.to(torch.float32).contiguous().to(device)
         self.slope = None if slope is None else slope.to(torch.float32).contiguous().to(device)
         self.cin, self.cout, self.k, self.stride, self.pad, self.bias_mode = cin, cout, k, stride, pad, bias_mode
+        self.w64 = None              # fr_conv_walk64_pack'ed weights (3x3 / s1, 64 input channels), IResNetHIP._pack_walk64
         self.c2 = 0                  # channels of a second input that enters through a 1x1 tap (fr_conv_args.x2): fused shortcut
 
 
@@ -227,6 +229,7 @@ class IResNetHIP:
                 self.fused_sc[i] = fz
         self._pack_stage14()
         self._pack_stage28()
+        self._pack_walk64()
         self.fc_w = f["fc_w"].to(torch.float16).contiguous().to(dev)
         self.fc_bias = f["fc_bias"].to(torch.float32).contiguous().to(dev)
         self.flops_per_face = self._count_flops()
@@ -268,6 +271,17 @@ class IResNetHIP:
                     prm[2 * k + j, 9] = c.slope if c.slope is not None else 1.0
             torch.cuda.synchronize(self.device)
         self.stage14 = {"first": best[0], "n": len(best), "w": stream, "prm": prm.contiguous()}
+
+    def _pack_walk64(self):
+        """Weights of the 3x3 / s1 convs with 64 input channels (112x112, 56x56) in fr_conv_walk64_f16's stream order."""
+        self.use_walk64 = True       # False: these convs on the per-tile halo kernel whatever the batch (A/B, tests)
+        with torch.cuda.device(self.device):
+            for c1, c2, _ in self.blocks:
+                for c in (c1, c2):
+                    if c.k == 3 and c.stride == 1 and c.cin == 64 and c.cout % 64 == 0:
+                        c.w64 = torch.empty(self.lib.fr_conv_walk64_weight_bytes(c.cout) // 2, dtype=torch.float16, device=self.device)
+                        self.lib.fr_conv_walk64_pack(_lib.ptr(c.w), _lib.ptr(c.w64), c.cout, _lib.stream_ptr())
+            torch.cuda.synchronize(self.device)
 
     # ---- the 28x28 stage's stride-1 blocks as one launch (fr_conv_stage28_f16)
     def _pack_stage28(self):
@@ -542,6 +556,19 @@ class IResNetHIP:
             return y, Ho, Wo
         if partial is None and y is None:
             y = torch.empty((B, Ho, Wo, c.cout), dtype=torch.float16, device=self.device)
+        if (self.use_walk64 and partial is None and x2 is None and H == W and H % 28 == 0 and B >= WALK64_MIN_BATCH
+                and getattr(c, "w64", None) is not None):
+            args = (_lib.ptr(x), _lib.ptr(c.w64), _lib.ptr(y), _lib.ptr(c.bias), c.bias_mode, _lib.ptr(c.slope),
+                    _lib.ptr(residual), B, H, c.cout, _lib.stream_ptr())
+            if self.profile is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.lib.fr_conv_walk64_f16(*args)
+                e1.record()
+                self.profile.append(("conv_walk64_kernel %dx%d -> %d" % (H, W, c.cout), 2.0 * B * H * W * c.cout * 576, e0, e1))
+            else:
+                self.lib.fr_conv_walk64_f16(*args)
+            return y, Ho, Wo
         a = _lib.ConvArgs(_lib.ptr(x), _lib.ptr(c.w) if isinstance(c, _Conv) else None, _lib.ptr(y),
                           _lib.ptr(c.bias), _lib.ptr(c.slope), _lib.ptr(residual), _lib.ptr(partial),
                           B, H, W, c.cin, c.cout, c.k, c.k, c.stride, c.pad, Ho, Wo, c.bias_mode, splitk,

@@ -201,6 +201,16 @@ int fr_conv_stage14_f16(const void* x, void* y, const void* wstream, const float
 size_t fr_conv_stage28_weight_bytes(int nconv);
 int fr_conv_stage28_pack(const void* w, void* out, fr_stream_t stream);
 int fr_conv_stage28_f16(void* x, void* mid, const void* wstream, const float* params, int B, int nblocks, fr_stream_t stream);
+/* 3x3 / stride 1 / pad 1 conv with 64 input channels on square images whose side is a multiple of 28 (IResNet-100: 112x112 and
+ * 56x56; embed half of FaceAnalysis.get, /root/reference/infrenceServer.py:528), one launch per layer: a workgroup walks one
+ * face (x one 64-cout group) region by region (14 x 28 output pixels), the next region's input halo arriving in a second LDS
+ * buffer under the current region's K loop (conv_walk64.hip).  Same arithmetic and argument meaning as fr_conv_nhwc_f16
+ * (bias_mode 1 = nine border-class biases [9][Cout]); wstream: the [Cout][9*64] f16 weights re-ordered by
+ * fr_conv_walk64_pack (fr_conv_walk64_weight_bytes(Cout) bytes); Cout % 64 == 0; y must not alias x; residual may alias y. */
+size_t fr_conv_walk64_weight_bytes(int Cout);
+int fr_conv_walk64_pack(const void* w, void* out, int Cout, fr_stream_t stream);
+int fr_conv_walk64_f16(const void* x, const void* wstream, void* y, const float* bias, int bias_mode, const float* slope,
+                       const void* residual, int B, int HW, int Cout, fr_stream_t stream);
 /* The fp8 twin of fr_conv_stage14_f16 (BASELINE config C5): the same run of residual blocks on
  * v_mfma_scale_f32_16x16x128_f8f6f4, the conv inputs as centred e4m3 codes resident in LDS (conv_stage14_f8.hip).  Math and
  * operation order of fr_conv_nhwc_f8 per conv: acc * oscale + 9-class bias -> PReLU -> (+ f16 residual) -> one rounding to

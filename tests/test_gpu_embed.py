@@ -326,6 +326,68 @@ def test_stage14_kernel_vs_torch(lib, B, nblocks):
     assert d.max().item() <= 2e-3 * ref.abs().max().item() and d.mean().item() < 1e-4 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("B,HW,cout,mode", [(1, 56, 64, "c1"), (2, 56, 64, "c2"), (1, 56, 128, "c1"), (1, 112, 64, "c1"), (3, 28, 64, "plain"),
+                                             (1, 84, 64, "c2")])
+def test_walk64_kernel_vs_torch_and_halo_kernel(lib, B, HW, cout, mode):
+    """fr_conv_walk64_f16 (a workgroup walks a face region by region, the next region's halo prefetched) against plain torch
+    fp32 on the same f16 operands and against fr_conv_nhwc_f16: conv1 form (9-class border bias + PReLU), conv2 form (bias +
+    residual aliasing the output), two cout groups, 112x112 (32 regions), one region per row band (28) and a 3 x 6 grid (84)."""
+    from facerecognition_infrenceengine_amd import _lib
+    g = torch.Generator().manual_seed(13 * HW + cout + B)
+    x = torch.randn((B, HW, HW, 64), generator=g).to(torch.float16)
+    w = (torch.randn((cout, 3, 3, 64), generator=g) * (2.0 / 576) ** 0.5).to(torch.float16)
+    rc = torch.ones(HW, dtype=torch.long); rc[0] = 0; rc[-1] = 2
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), None, 1, 1)
+    bias = slope = res = None
+    if mode == "c1":
+        bias = torch.randn((3, 3, cout), generator=g) * 0.3
+        slope = torch.rand(cout, generator=g) * 0.5
+        ref = ref + bias[rc][:, rc].permute(2, 0, 1)[None]
+        ref = torch.where(ref > 0, ref, ref * slope[None, :, None, None])
+    elif mode == "c2":
+        bias = torch.randn(cout, generator=g) * 0.1
+        res = torch.randn((B, HW, HW, cout), generator=g).to(torch.float16)
+        ref = ref + bias[None, :, None, None] + res.float().permute(0, 3, 1, 2)
+    ref = ref.permute(0, 2, 3, 1)
+    xd, wd = x.cuda(), w.reshape(cout, 576).contiguous().cuda()
+    bd = None if bias is None else bias.reshape(-1).contiguous().cuda()
+    sd = None if slope is None else slope.cuda()
+    ws = torch.empty(lib.fr_conv_walk64_weight_bytes(cout) // 2, dtype=torch.float16, device="cuda")
+    lib.fr_conv_walk64_pack(_lib.ptr(wd), _lib.ptr(ws), cout, _lib.stream_ptr())
+    y = torch.full((B, HW, HW, cout), float("nan"), dtype=torch.float16, device="cuda") if res is None else res.cuda()
+    lib.fr_conv_walk64_f16(_lib.ptr(xd), _lib.ptr(ws), _lib.ptr(y), _lib.ptr(bd), 1 if mode == "c1" else 0, _lib.ptr(sd),
+                           _lib.ptr(y) if res is not None else None, B, HW, cout, _lib.stream_ptr())
+    y2 = torch.empty((B, HW, HW, cout), dtype=torch.float16, device="cuda")
+    a = _lib.ConvArgs(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y2), _lib.ptr(bd), _lib.ptr(sd), _lib.ptr(res.cuda()) if res is not None else None,
+                      None, B, HW, HW, 64, cout, 3, 3, 1, 1, HW, HW, 1 if mode == "c1" else 0, 1, None, 0)
+    lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err <= 2e-3 * scale, (err, scale)
+    d = (y.float() - y2.float()).abs()
+    assert d.max().item() <= 2e-3 * scale and d.mean().item() < 1e-4 * scale
+
+
+def test_walk64_path_on_r100_equals_halo_path(r100):
+    """From 144 faces up the six 3x3 / s1 convs with 64 input channels run on fr_conv_walk64_f16: same embeddings as on the
+    per-tile halo kernel to f16 rounding noise."""
+    g = torch.Generator().manual_seed(64)
+    xa = nchw_to_nhwc8(torch.rand((145, 3, 112, 112), generator=g) * 2 - 1)
+    r100.profile = []
+    _, n1 = r100.forward(xa)
+    names = [p[0] for p in r100.profile]
+    r100.profile = None
+    assert sum(nm.startswith("conv_walk64_kernel") for nm in names) == 6
+    r100.use_walk64 = False
+    try:
+        _, n0 = r100.forward(xa)
+    finally:
+        r100.use_walk64 = True
+    torch.cuda.synchronize()
+    assert (1 - (n0 * n1).sum(1)).max().item() < 2e-5
+
+
 @pytest.mark.parametrize("B,nblocks", [(1, 1), (3, 2), (5, 3)])
 def test_stage28_kernel_vs_torch(lib, B, nblocks):
     """fr_conv_stage28_f16 (one workgroup walks a face through all convs of the 28x28 run, half an image per pass, maps
