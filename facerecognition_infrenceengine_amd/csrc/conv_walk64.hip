@@ -40,6 +40,7 @@ struct Walk64P {
     const half_t* x; const half_t* w; half_t* y;
     const float* bias; const float* slope; const half_t* res;
     int B, HW, Cout, bias_mode;                                      // HW: image height = width (56 or 112)
+    int nsplit;                                                      // workgroups per (face, cout group): each walks nreg / nsplit regions
     unsigned xbytes, ybytes, wbytes;
 };
 
@@ -59,8 +60,9 @@ __global__ __launch_bounds__(512, 2) void conv_walk64_kernel(Walk64P p) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ncg = p.Cout >> 6;
-    const int cg = blockIdx.x % ncg, n = blockIdx.x / ncg;            // cout groups of a face next to each other: they share its input in L2
-    const int HW = p.HW, nbx = HW / K64_RW, nreg = nbx * (HW / K64_RH);
+    const int cg = blockIdx.x % ncg, part = (blockIdx.x / ncg) % p.nsplit, n = blockIdx.x / (ncg * p.nsplit);   // cout groups of a face next to each other: they share its input in L2
+    const int HW = p.HW, nbx = HW / K64_RW;
+    const int reg0 = part * (nbx * (HW / K64_RH) / p.nsplit), nreg = reg0 + nbx * (HW / K64_RH) / p.nsplit;       // this workgroup's regions: [reg0, nreg)
 
     __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
     __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void conv_walk64_kernel(Walk64P p) {
         issue_w(0, ln);
         issue_w(1, ln);
         issue_w(2, ln);
-        for (int i = 0; i < 8; ++i) issue_halo(0, i, 0, ln);
+        for (int i = 0; i < 8; ++i) issue_halo(reg0 & 1, i, reg0, ln);
         // parameters of this cout group: 9 bias rows (bias_mode 0: the same row nine times) + slope (none: 1.0)
         for (int e = tid; e < 640; e += 512) {
             const int r = e >> 6, c = e & 63;
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void conv_walk64_kernel(Walk64P p) {
     auto run = [&](auto role_tag) {
     constexpr int ROLE = decltype(role_tag)::value;                  // wave >> 2: which SIMD partner this wave is
 #pragma unroll 1
-    for (int reg = 0; reg < nreg; ++reg) {
+    for (int reg = reg0; reg < nreg; ++reg) {
         const int cur = reg & 1;
         int lane = tid & 63;
         asm volatile("" : "+v"(lane));                               // lane constants re-derived per region: nothing hoisted into scratch
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void conv_walk64_kernel(Walk64P p) {
 
         // ---- accumulators: the pixel's border-class bias (+ residual)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (reg == 0) __builtin_amdgcn_s_barrier();                  // the parameter rows written above
+        if (reg == reg0) __builtin_amdgcn_s_barrier();               // the parameter rows written above
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int cj = cls_off((wave * 3 + t) * 16 + fr);
@@ -316,6 +318,10 @@ extern "C" int fr_conv_walk64_f16(const void* x, const void* wstream, void* y, c
     p.x = (const half_t*)x; p.w = (const half_t*)wstream; p.y = (half_t*)y;
     p.bias = bias; p.slope = slope; p.res = (const half_t*)residual;
     p.B = B; p.HW = HW; p.Cout = Cout; p.bias_mode = bias_mode;
+    // fewer (face, cout group) pairs than CUs: cut a face's walk into 2 / 4 / 8 pieces (a piece keeps >= 2 regions: the prefetch)
+    const int nregs = (HW / 28) * (HW / 14);
+    p.nsplit = 1;
+    while (p.nsplit < 8 && (int64_t)B * (Cout / 64) * p.nsplit * 2 <= 256 && nregs % (p.nsplit * 2) == 0 && nregs / (p.nsplit * 2) >= 2) p.nsplit *= 2;
     p.xbytes = (unsigned)((int64_t)B * HW * HW * 64 * 2);
     p.ybytes = (unsigned)((int64_t)B * HW * HW * Cout * 2);
     p.wbytes = (unsigned)((int64_t)(Cout / 64) * 9 * K64_SLOT);
@@ -324,7 +330,7 @@ extern "C" int fr_conv_walk64_f16(const void* x, const void* wstream, void* y, c
         fr_set_error("fr_conv_walk64_f16: cannot raise dynamic LDS to %d bytes", K64_LDS);
         return FR_E_LAUNCH;
     }
-    conv_walk64_kernel<<<B * (Cout / 64), 512, K64_LDS, fr_stream(stream)>>>(p);
+    conv_walk64_kernel<<<B * (Cout / 64) * p.nsplit, 512, K64_LDS, fr_stream(stream)>>>(p);
     FR_CHECK_LAUNCH("conv_walk64_kernel");
     return FR_OK;
 }

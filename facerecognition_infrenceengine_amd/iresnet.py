@@ -37,7 +37,11 @@ MAX_PLAN_STREAMS = 8
 # (fr_conv_stage14_f16: one workgroup per image, one image per CU); below, the per-layer path fills the CUs better
 # (measured r100 forward, stage / layer by layer: 128 faces 4.62 / 4.44 ms, 160: 5.16 / 5.74, 192: 5.49 / 6.17, 256: 6.8 / 7.6)
 STAGE14_MIN_BATCH = 144
-WALK64_MIN_BATCH = 144      # fr_conv_walk64_f16: one workgroup per (face, 64-cout group)
+# fr_conv_walk64_f16: one workgroup per (face, 64-cout group), a face's walk cut into 2 / 4 / 8 pieces while that fills <= 256
+# CUs.  Measured (tools/bench_walk64_crossover.py, r100 forward): it beats the per-tile kernel at 64 / 96 / 128 faces (cut walks) and
+# from 160 up; between 129 and 159 faces an uncut walk leaves 40 % of the CUs idle and loses by 1 %.  Not in the small-batch
+# modes (<= small_batch faces: the prepared single-frame sequence runs fr_conv_nhwc_f16, and a mode's kernels are one set).
+WALK64_SKIP = range(129, 160)
 STAGE28_MIN_BATCH = 144     # fr_conv_stage28_f16: one workgroup per face, as the 14x14 stage kernel
 
 
@@ -556,7 +560,7 @@ class IResNetHIP:
             return y, Ho, Wo
         if partial is None and y is None:
             y = torch.empty((B, Ho, Wo, c.cout), dtype=torch.float16, device=self.device)
-        if (self.use_walk64 and partial is None and x2 is None and H == W and H % 28 == 0 and B >= WALK64_MIN_BATCH
+        if (self.use_walk64 and partial is None and x2 is None and H == W and H % 28 == 0 and B > self.small_batch and B not in WALK64_SKIP
                 and getattr(c, "w64", None) is not None):
             args = (_lib.ptr(x), _lib.ptr(c.w64), _lib.ptr(y), _lib.ptr(c.bias), c.bias_mode, _lib.ptr(c.slope),
                     _lib.ptr(residual), B, H, c.cout, _lib.stream_ptr())

@@ -327,11 +327,12 @@ def test_stage14_kernel_vs_torch(lib, B, nblocks):
 
 
 @pytest.mark.parametrize("B,HW,cout,mode", [(1, 56, 64, "c1"), (2, 56, 64, "c2"), (1, 56, 128, "c1"), (1, 112, 64, "c1"), (3, 28, 64, "plain"),
-                                             (1, 84, 64, "c2")])
+                                             (1, 84, 64, "c2"), (130, 56, 64, "c2"), (40, 56, 64, "c1")])
 def test_walk64_kernel_vs_torch_and_halo_kernel(lib, B, HW, cout, mode):
     """fr_conv_walk64_f16 (a workgroup walks a face region by region, the next region's halo prefetched) against plain torch
     fp32 on the same f16 operands and against fr_conv_nhwc_f16: conv1 form (9-class border bias + PReLU), conv2 form (bias +
-    residual aliasing the output), two cout groups, 112x112 (32 regions), one region per row band (28) and a 3 x 6 grid (84)."""
+    residual aliasing the output), two cout groups, 112x112 (32 regions), one region per row band (28) and a 3 x 6 grid (84);
+    few faces cut a face's walk into up to 8 pieces, 130 faces walk uncut, 40 faces in 4 pieces."""
     from facerecognition_infrenceengine_amd import _lib
     g = torch.Generator().manual_seed(13 * HW + cout + B)
     x = torch.randn((B, HW, HW, 64), generator=g).to(torch.float16)
@@ -370,10 +371,10 @@ def test_walk64_kernel_vs_torch_and_halo_kernel(lib, B, HW, cout, mode):
 
 
 def test_walk64_path_on_r100_equals_halo_path(r100):
-    """From 144 faces up the six 3x3 / s1 convs with 64 input channels run on fr_conv_walk64_f16: same embeddings as on the
-    per-tile halo kernel to f16 rounding noise."""
+    """The six 3x3 / s1 convs with 64 input channels run on fr_conv_walk64_f16 (here 100 faces: a face's walk cut in two): same
+    embeddings as on the per-tile halo kernel to f16 rounding noise."""
     g = torch.Generator().manual_seed(64)
-    xa = nchw_to_nhwc8(torch.rand((145, 3, 112, 112), generator=g) * 2 - 1)
+    xa = nchw_to_nhwc8(torch.rand((100, 3, 112, 112), generator=g) * 2 - 1)
     r100.profile = []
     _, n1 = r100.forward(xa)
     names = [p[0] for p in r100.profile]

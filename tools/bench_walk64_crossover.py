@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from facerecognition_infrenceengine_amd import weights, iresnet
 from facerecognition_infrenceengine_amd.iresnet import IResNetHIP
-iresnet.WALK64_MIN_BATCH = 1
+iresnet.WALK64_SKIP = range(0)
 net = IResNetHIP(weights.synth_iresnet_state("r100"), "r100", "cuda:0")
 for B in (64, 96, 128, 144, 160, 192, 224, 256):
     x = (torch.rand((B, 112, 112, 8), device="cuda") * 2 - 1).half(); x[..., 3:] = 0
