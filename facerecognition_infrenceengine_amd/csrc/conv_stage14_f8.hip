@@ -212,31 +212,34 @@ __global__ __launch_bounds__(512, 2) void conv_stage14_f8_kernel(StageF8P p) {
             // ago - L1-bypassing loads (sc1): a CU's vector L1 is never refreshed by stores.
             __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)(conv == 1 ? p.x16 : (const half_t*)p.y16), 0, p.xbytes16, 0x00020000);
             const unsigned rb = (unsigned)n * (unsigned)(F14_PX * F14_C * 2);
-            int2v r[6][4], rx[2];
+            // 16 B per lane = 8 consecutive couts: lanes fq = 0, 2 / 1, 3 fetch couts 0..7 / 8..15 of cout tiles (2 ip, 2 ip + 1) and
+            // v_permlane16_swap puts them back into the accumulator layout (a vector-memory instruction costs the same whatever
+            // its width, and L1-bypassing 8-byte loads at a 512-byte stride are one L2 request per lane)
+            int4v r[6][2], rx;
+            const int co8 = wn * 64 + (fqe & 1) * 16 + (fqe >> 1) * 8;      // + 32 per tile pair
 #pragma unroll
             for (int j = 0; j < 6; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    r[j][i] = __builtin_bit_cast(int2v, __builtin_amdgcn_raw_buffer_load_b64(rrs, (unsigned)((px0e + 16 * j) * F14_C + co_own + i * 16) * 2, rb, 16));
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-                rx[t] = __builtin_bit_cast(int2v, __builtin_amdgcn_raw_buffer_load_b64(rrs, 192 + fre < F14_PX ? (unsigned)((192 + fre) * F14_C + co_sh + t * 16) * 2 : 0x80000000u, rb, 16));
+                for (int ip = 0; ip < 2; ++ip)
+                    r[j][ip] = __builtin_bit_cast(int4v, __builtin_amdgcn_raw_buffer_load_b128(rrs, (unsigned)((px0e + 16 * j) * F14_C + co8 + ip * 32) * 2, rb, 16));
+            rx = __builtin_bit_cast(int4v, __builtin_amdgcn_raw_buffer_load_b128(rrs, 192 + fre < F14_PX ? (unsigned)((192 + fre) * F14_C + co8 + WP * 32) * 2 : 0x80000000u, rb, 16));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the parameters (1 / oscale) and the residual
             __builtin_amdgcn_s_barrier();
+            auto unswap = [&](const int4v& v, float4v& lo, float4v& hi, int co_lo) {
+                const auto s0 = __builtin_amdgcn_permlane16_swap((unsigned)v[0], (unsigned)v[2], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap((unsigned)v[1], (unsigned)v[3], false, false);
+                const half4 ha = __builtin_bit_cast(half4, int2v{(int)s0[0], (int)s1[0]});
+                const half4 hb = __builtin_bit_cast(half4, int2v{(int)s0[1], (int)s1[1]});
+                const float4v ia = *reinterpret_cast<const float4v*>(lprm + PR_INVOSCALE * F14_C + co_lo);
+                const float4v ib = *reinterpret_cast<const float4v*>(lprm + PR_INVOSCALE * F14_C + co_lo + 16);
+                lo = float4v{(float)ha[0] * ia[0], (float)ha[1] * ia[1], (float)ha[2] * ia[2], (float)ha[3] * ia[3]};
+                hi = float4v{(float)hb[0] * ib[0], (float)hb[1] * ib[1], (float)hb[2] * ib[2], (float)hb[3] * ib[3]};
+            };
 #pragma unroll
             for (int j = 0; j < 6; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const half4 h = __builtin_bit_cast(half4, r[j][i]);
-                    const float4v io = *reinterpret_cast<const float4v*>(lprm + PR_INVOSCALE * F14_C + co_own + i * 16);
-                    acc[j][i] = float4v{(float)h[0] * io[0], (float)h[1] * io[1], (float)h[2] * io[2], (float)h[3] * io[3]};
-                }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const half4 h = __builtin_bit_cast(half4, rx[t]);
-                const float4v io = *reinterpret_cast<const float4v*>(lprm + PR_INVOSCALE * F14_C + co_sh + t * 16);
-                accx[t] = float4v{(float)h[0] * io[0], (float)h[1] * io[1], (float)h[2] * io[2], (float)h[3] * io[3]};
-            }
+                for (int ip = 0; ip < 2; ++ip) unswap(r[j][ip], acc[j][2 * ip], acc[j][2 * ip + 1], co_own + ip * 32);
+            unswap(rx, accx[0], accx[1], co_sh);
         } else {
 #pragma unroll
             for (int j = 0; j < 6; ++j)
@@ -292,30 +295,52 @@ __global__ __launch_bounds__(512, 2) void conv_stage14_f8_kernel(StageF8P p) {
         const int ch_own = (wn & 1) * 4, ch_sh = (wn & 1) * 4 + WP * 2;                  // 16-B chunk inside the plane row: + 1 per cout tile
         const float inv_sx = lprm[PR_INVSX * F14_C];
         half_t* ybase = p.y16 + (size_t)n * (F14_PX * F14_C);
+        // Tile pairs (cout tiles 2 ip, 2 ip + 1) outermost: the per-cout parameters (oscale, centre, slope) are read once per
+        // PAIR - 12 + 6 b128 LDS reads per wave instead of 78 - and only 24 registers of them are live at a time (hoisting all
+        // six cout tiles' parameters in front of the loop cost the K loop 16 more spilled registers and 80 % more cycles per step);
+        // a second conv's f16 result leaves as one 16-byte store per pair (v_permlane16_swap, as the residual comes in).
+        const int co8e = wn * 64 + (fqe & 1) * 16 + (fqe >> 1) * 8;
         auto tiles = [&](auto first_tag) {
             constexpr bool FIRST = decltype(first_tag)::value;
 #pragma unroll
-            for (int t = 0; t < 26; ++t) {
-                const float4v a_ = t < 24 ? acc[t >> 2][t & 3] : accx[t - 24];
-                const int j = t < 24 ? t >> 2 : 6, co = t < 24 ? co_o + (t & 3) * 16 : co_s + (t - 24) * 16;
-                const int ch = t < 24 ? ch_own + (t & 3) : ch_sh + (t - 24);
-                float4v v = a_ * *reinterpret_cast<const float4v*>(lprm + PR_OSCALE * F14_C + co);
-                v += *reinterpret_cast<const float4v*>(lprm + clsoff[j] + co);
-                if constexpr (FIRST) {
-                    const float4v s_ = *reinterpret_cast<const float4v*>(lprm + PR_SLOPE * F14_C + co);
+            for (int ip = 0; ip < 3; ++ip) {                         // ip 2: the shared pixel tile's two cout tiles
+                float4v osc[2], mu2[2], slp[2];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * s_[e];
+                for (int u = 0; u < 2; ++u) {
+                    const int co = ip < 2 ? co_o + (2 * ip + u) * 16 : co_s + u * 16;
+                    osc[u] = *reinterpret_cast<const float4v*>(lprm + PR_OSCALE * F14_C + co);
+                    mu2[u] = *reinterpret_cast<const float4v*>(lprm + PR_MU * F14_C + co);
+                    if constexpr (FIRST) slp[u] = *reinterpret_cast<const float4v*>(lprm + PR_SLOPE * F14_C + co);
                 }
-                const half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                const bool live = t < 24 || 192 + fre < F14_PX;
-                if constexpr (!FIRST) {
-                    if (live) *reinterpret_cast<half4*>(ybase + gpix[j] + co) = h;      // the residual stream / the result
+#pragma unroll
+                for (int jj = 0; jj < (ip < 2 ? 6 : 1); ++jj) {
+                    const int j = ip < 2 ? jj : 6;
+                    const bool live = ip < 2 || 192 + fre < F14_PX;
+                    int2v hp[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const float4v a_ = ip < 2 ? acc[jj][2 * ip + u] : accx[u];
+                        const int co = ip < 2 ? co_o + (2 * ip + u) * 16 : co_s + u * 16;
+                        const int ch = ip < 2 ? ch_own + 2 * ip + u : ch_sh + u;
+                        float4v v = a_ * osc[u];
+                        v += *reinterpret_cast<const float4v*>(lprm + clsoff[j] + co);
+                        if constexpr (FIRST) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slp[u][e];
+                        }
+                        const half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        hp[u] = __builtin_bit_cast(int2v, h);
+                        const int code = pack_fp8x4_sat(((float)h[0] - mu2[u][0]) * inv_sx, ((float)h[1] - mu2[u][1]) * inv_sx,
+                                                        ((float)h[2] - mu2[u][2]) * inv_sx, ((float)h[3] - mu2[u][3]) * inv_sx);
+                        if (live) *reinterpret_cast<int*>(img + rowoff[j] + ((ch ^ key[j]) << 4)) = code;
+                    }
+                    if constexpr (!FIRST) {                          // the residual stream / the result
+                        const auto s0 = __builtin_amdgcn_permlane16_swap((unsigned)hp[0][0], (unsigned)hp[1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap((unsigned)hp[0][1], (unsigned)hp[1][1], false, false);
+                        if (live) *reinterpret_cast<int4v*>(ybase + gpix[j] + co8e + (ip < 2 ? ip * 32 : WP * 32)) = int4v{(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
+                    }
+                    F14_PIN();
                 }
-                const float4v mu = *reinterpret_cast<const float4v*>(lprm + PR_MU * F14_C + co);
-                const int code = pack_fp8x4_sat(((float)h[0] - mu[0]) * inv_sx, ((float)h[1] - mu[1]) * inv_sx,
-                                                ((float)h[2] - mu[2]) * inv_sx, ((float)h[3] - mu[3]) * inv_sx);
-                if (live) *reinterpret_cast<int*>(img + rowoff[j] + ((ch ^ key[j]) << 4)) = code;
-                if ((t & 3) == 3) F14_PIN();
             }
         };
         if (second) tiles(std::false_type{}); else tiles(std::true_type{});
