@@ -119,6 +119,7 @@ def _dense_as_conv(w, k, c):
 
 
 class MTCNNHIP:
+    SINGLE_FRAME_LEVEL_STREAMS = 11     # level streams of a single-frame call while it is captured into a HIP graph
     def __init__(self, pstate, rstate, ostate, device="cuda:0", minsize=20, factor=0.709,
                  thresholds=(0.6, 0.7, 0.7), cap_scale=2048, keep_scale=256, cap_p=512, cap_r=64, cap_o=16,
                  fused_pnet=True):
@@ -132,6 +133,7 @@ class MTCNNHIP:
         self._tls = threading.local()      # per-thread launch stream: detect_batch is re-entrant across threads
         self.one_stream = False            # True (profiling): every pyramid level on the caller's stream, per-kernel times add up
         self.level_streams = 1             # side streams the pyramid levels 1.. are dealt over (detect_batch's default)
+        self.single_frame_level_streams = self.SINGLE_FRAME_LEVEL_STREAMS      # the same for batches of < 8 frames (0: as level_streams)
         self.phase_marks = None            # tools: a list -> (name, event on the caller's stream) at the cascade's phase ends
         self.merged_level_nms = True       # the per-level NMS of ALL levels as one launch behind the pyramid (False: one per level)
         d = self.device
@@ -329,7 +331,16 @@ class MTCNNHIP:
             sides = self._sides.get(main.cuda_stream)         # side streams per caller stream: independent
             if sides is None:                                 # pipelines (bench --pipes) do not couple through them
                 sides = self._sides[main.cuda_stream] = [torch.cuda.Stream(device=self.device) for _ in range(2)]
-            sides = sides[:max(1, min(2, level_streams if level_streams is not None else self.level_streams))]
+            nside = max(1, min(2, level_streams if level_streams is not None else self.level_streams))
+            if N < 8 and level_streams is None and self.single_frame_level_streams > 0 and torch.cuda.is_current_stream_capturing():
+                # A single frame is a chain of launch latencies.  While a HIP graph is being captured, every level goes to a
+                # stream of its own: the graph then holds the levels' five-kernel chains side by side (640x480 get() + match
+                # under replay 2.21 -> 2.01 ms).  Not in eager calls: the host issues the launches one by one anyway and the
+                # extra fork / join events cost it 0.1 ms.
+                nside = min(self.single_frame_level_streams, max(1, nlev - 1))
+                while len(sides) < nside:
+                    sides.append(torch.cuda.Stream(device=self.device))
+            sides = sides[:nside]
             for side in sides:
                 side.wait_stream(main)
             for li, s in enumerate(scales):
