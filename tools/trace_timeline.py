@@ -10,7 +10,7 @@ t0 = last - 150_000_000
 ev = [e for e in ev if e[0] >= t0 and e[1] <= last]
 def kind(n):
     if "dconv" in n or "pnet" in n or "sort_nms" in n or "crop_resize" in n or "stage_select" in n or "box_refine" in n: return "D"
-    if "conv_halo" in n or "conv_mfma" in n or "fc_reduce" in n or "warp_affine" in n: return "E"
+    if "conv_" in n or "fc_reduce" in n or "warp_affine" in n: return "E"
     if "zzz" in n or "pnet" in n or "sort_nms" in n or "crop_resize" in n or "stage_select" in n or "box_refine" in n: return "D"
     if "gallery" in n or "l2norm" in n or "match_decide" in n: return "M"
     if "copyBuffer" in n or "nccl" in n.lower(): return "C"
