@@ -197,7 +197,9 @@ __global__ __launch_bounds__(256, RPW == 4 ? 3 : 6) void pnet_conv1_kernel(P1Arg
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float sv = bilerp(a00[c], two ? a01[c] : a00[c], a10[c], two ? a11[c] : a10[c], wx[u], wy[u]);
-                v[c] = (!E || rfl[u] >= 0) && !(P1_ABL & 4) ? (sv - 127.5f) * 0.0078125f : 0.f;
+                // (sv - 127.5) * 2^-7 as ONE fma: scaling by a power of two commutes with the rounding of the difference (no
+                // subnormals here: |sv - 127.5| >= 2^-17 or 0), so the bits are those of the two-operation form
+                v[c] = (!E || rfl[u] >= 0) && !(P1_ABL & 4) ? __builtin_fmaf(sv, 0.0078125f, -0.99609375f) : 0.f;
             }
             xin[e * 3 + 0] = v[0]; xin[e * 3 + 1] = v[1]; xin[e * 3 + 2] = v[2];
         }

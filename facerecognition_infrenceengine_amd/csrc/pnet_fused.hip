@@ -44,6 +44,9 @@ struct P23Args {
     const float* hw; const float* hb;     // heads: hw [32][6], hb [6]
     float* head;                          // f32 [B, H3, W3, 6] = (logit0, logit1, reg0..3)
     float* dl;                            // f32 [B, H3, W3]: logit1 - logit0 (what the re-evaluation pass scans)
+    int all_heads;                        // 0: only `dl` is written (the exact pass writes the heads of every cell that can be kept)
+    int* list; int* counts; int seg_cap;  // cells with dl >= logit_thr, appended by block b to list[b * seg_cap ..] (counts[b] of them):
+    float logit_thr;                      // the work list of the exact pass - no global atomics, no second scan of dl
     int B, H1, W1, H3, W3, tiles_x, tiles_y, ntiles;
 };
 
@@ -63,6 +66,7 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
     char* x2t = x1t + 2 * P23_X1PL;                         // hi plane [340 px][32 B] | lo plane
     char* wf = x2t + 2 * P23_X2PL;                          // fragments: conv2 [5 ks][2 planes][64 lanes][16 B], conv3 [2 ct][5][2][64][16]
     float* cst = reinterpret_cast<float*>(wf + 30 * 1024);  // b2[16] s2[16] b3[32] s3[32] hb[8]
+    int* lcnt = reinterpret_cast<int*>(cst + 104);           // cells this block has appended to its list segment
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
 
@@ -85,6 +89,8 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
     for (int e = tid; e < 16; e += P23_NT) { cst[e] = a.b2[e]; cst[16 + e] = a.s2[e]; }
     for (int e = tid; e < 32; e += P23_NT) { cst[32 + e] = a.b3[e]; cst[64 + e] = a.s3[e]; }
     for (int e = tid; e < 8; e += P23_NT) cst[96 + e] = e < 6 ? a.hb[e] : 0.f;
+    if (tid == 0) *lcnt = 0;
+    int* const seg = a.list + (size_t)blockIdx.x * a.seg_cap;
 
     // per-lane tap offsets of the 5 K steps (lane quarter fq < 2: tap 2ks, else tap 2ks+1; tap 9 does not exist: its
     // weights are zero, it reads tap 8's pixels)
@@ -245,178 +251,220 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
                 // d[r] = head 4*fq + r of pixel fr (heads 6..15 are zero rows)
                 const int q = (wave * 2 + t) * 16 + fr;
                 const int gy = ty0 + (q >> 5), gx = tx0 + (q & 31);
-                if (fq < 2 && gy < a.H3 && gx < a.W3) {
-                    const size_t cell = ((size_t)n * a.H3 + gy) * a.W3 + gx;
-                    float* o = a.head + cell * 6 + 4 * fq;
-                    const float4v hb4 = *reinterpret_cast<const float4v*>(cst + 96 + 4 * fq);
-                    const float o0 = d[0] + hb4[0], o1 = d[1] + hb4[1];
-                    *reinterpret_cast<float2*>(o) = make_float2(o0, o1);
-                    if (fq == 0) {
-                        *reinterpret_cast<float2*>(o + 2) = make_float2(d[2] + hb4[2], d[3] + hb4[3]);
-                        a.dl[cell] = o1 - o0;
+                const bool inb = fq < 2 && gy < a.H3 && gx < a.W3;
+                const size_t cell = ((size_t)n * a.H3 + gy) * a.W3 + gx;
+                const float4v hb4 = *reinterpret_cast<const float4v*>(cst + 96 + 4 * (fq & 1));
+                const float o0 = d[0] + hb4[0], o1 = d[1] + hb4[1];
+                // the exact pass's work list: one LDS atomic per wave and pixel tile that holds a flagged cell
+                const bool flag = inb && fq == 0 && (o1 - o0) >= a.logit_thr;
+                const unsigned long long fm = __ballot(flag);
+                if (fm) {
+                    int base = 0;
+                    if (lane == (int)__builtin_ctzll(fm)) base = atomicAdd(lcnt, (int)__builtin_popcountll(fm));
+                    base = __shfl(base, (int)__builtin_ctzll(fm), 64);
+                    if (flag) seg[base + (int)__builtin_popcountll(fm & ((1ull << lane) - 1ull))] = (int)cell;
+                }
+                if (inb) {
+                    if (fq == 0) a.dl[cell] = o1 - o0;
+                    // the approximate heads themselves are read by nobody in the product path (fr_pnet_candidates skips the
+                    // cells below the margin, the exact pass overwrites the others): 24 B per cell of HBM writes saved
+                    if (a.all_heads) {
+                        float* o = a.head + cell * 6 + 4 * fq;
+                        *reinterpret_cast<float2*>(o) = make_float2(o0, o1);
+                        if (fq == 0) *reinterpret_cast<float2*>(o + 2) = make_float2(d[2] + hb4[2], d[3] + hb4[3]);
                     }
                 }
             }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) a.counts[blockIdx.x] = *lcnt;
+#endif
+}
+
+// ---------------------------------------------------------------- exact f32 re-evaluation of the cells that matter
+// Block b re-evaluates the cells pnet23's block b appended to its list segment (dl >= logit_thr; no scan of dl, no global
+// atomics: a single global counter saturates at ~90 appends/us), SIXTEEN per wave on the f32 matrix instruction
+// v_mfma_f32_16x16x4_f32 with exactly the K-step composition of the all-f32 path (dconv_mfma.hip, layers 1 and 2):
+//   conv2  D[cout][cell] per 3x3 position p: 27 steps (tap, 4 channels), A = w2[cout][tap][4 c4 + kq] (registers),
+//          B = the cell's conv1 window [5][5][12] in LDS, pixel (py + ty, px + tx), channel 4 c4 + kq
+//   conv3  36 steps (tap = position, 4 channels) on the PReLU'd conv2 tile (through LDS: D rows are couts 4 kq + r, a
+//          B operand wants channel 4 c4 + kq), 2 cout tiles
+//   heads  as dconv_mfma's fused head: conv3's D tile IS a B operand once one register e is taken at a time (k slot
+//          kq <-> channel 16 i + 4 kq + e), the accumulator starts as the head bias
+// so a re-evaluated cell carries the bits the all-f32 path computes.  (The first form was a VALU fma chain, 16 lanes
+// per cell, 4 cells per wave, behind a per-block scan of dl: 0.59 ms per 64 x 1080p batch for 167 k cells.)
+#define PREF_WS 304                                        // floats per cell slot in LDS: 5 x 5 x 12 window (300), 16-B rows
+struct PRefArgs {
+    const float* x1; const float* w2; const float* b2; const float* s2; const float* w3; const float* b3; const float* s3;
+    const float* hw; const float* hb; float* head;
+    const int* list; const int* counts; int seg_cap;       // pnet23's per-block lists of cells with logit1 - logit0 >= logit_thr
+    int B, H1, W1, H3, W3;
+    int* counter;                                          // optional: accumulated number of re-evaluated cells (diagnostics), or NULL
+};
+
+__global__ __launch_bounds__(256, 2) void pnet_refine_mfma(PRefArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) float wins[4][16 * PREF_WS];          // per wave: 16 cells' windows, then their conv2 tiles
+    __shared__ int cbase[4][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    float* win = wins[wave];
+    if (a.counts[blockIdx.x] == 0) return;                  // block-uniform, before any barrier
+    // ---- weights as A operands: lane (row li, k slot kq)
+    float wa2[27], wa3[2][36], hwa[8];
+#pragma unroll
+    for (int s = 0; s < 27; ++s) wa2[s] = a.w2[(li * 10 + s / 3) * 16 + 4 * (s % 3) + kq];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int s = 0; s < 36; ++s) wa3[i][s] = a.w3[((16 * i + li) * 10 + s / 4) * 16 + 4 * (s % 4) + kq];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hwa[i * 4 + e] = li < 6 ? a.hw[(16 * i + 4 * kq + e) * 6 + li] : 0.f;
+    const float4v b2 = *reinterpret_cast<const float4v*>(a.b2 + 4 * kq), s2 = *reinterpret_cast<const float4v*>(a.s2 + 4 * kq);
+    float4v b3[2], s3[2], hb4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        b3[i] = *reinterpret_cast<const float4v*>(a.b3 + 16 * i + 4 * kq);
+        s3[i] = *reinterpret_cast<const float4v*>(a.s3 + 16 * i + 4 * kq);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hb4[r] = kq * 4 + r < 6 ? a.hb[kq * 4 + r] : 0.f;
+
+    const int hw3 = a.H3 * a.W3;
+    {
+        const int* lst = a.list + (size_t)blockIdx.x * a.seg_cap;
+        const int n_list = a.counts[blockIdx.x];
+        if (a.counter && tid == 0 && n_list) atomicAdd(a.counter, n_list);
+        // wave w takes the cells [i0 + 16 w, + 16) of the list; slots past its end repeat the last cell and store nothing
+        for (int i0 = wave * 16; i0 < n_list; i0 += 64) {
+            {
+                const int c = lst[min(i0 + li, n_list - 1)];
+                const int n = c / hw3, r = c - n * hw3, y = r / a.W3, x = r - y * a.W3;
+                if (kq == 0) cbase[wave][li] = ((n * a.H1 + y) * a.W1 + x) * 12;  // conv1 window corner of the cell (floats)
+            }
+            __builtin_amdgcn_wave_barrier();
+            // the trip's 16 x 75 float4 window pieces, 19 per lane: piece -> (cell slot, window row, 16-B chunk); derived here
+            // from one opaque register per trip (hoisted out of the span loop they would be 57 registers held - or spilled -
+            // across everything)
+            int l_ = lane;
+            asm volatile("" : "+v"(l_));
+            float4v pf[19];
+#pragma unroll
+            for (int it = 0; it < 19; ++it) {
+                const int idx = min(it * 64 + l_, 1199);
+                const int j = idx / 75, rem = idx - j * 75, row = rem / 15, c4 = rem - row * 15;
+                pf[it] = *reinterpret_cast<const float4v*>(a.x1 + (size_t)(unsigned)cbase[wave][j] + (row * a.W1 * 12 + c4 * 4));
+            }
+#pragma unroll
+            for (int it = 0; it < 19; ++it) {
+                const int idx = it * 64 + l_;
+                const int j = idx / 75, rem = idx - j * 75, row = rem / 15, c4 = rem - row * 15;
+                if (it < 18 || l_ < 48) *reinterpret_cast<float4v*>(win + j * PREF_WS + row * 60 + c4 * 4) = pf[it];
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- conv2 at the 3 x 3 positions
+            const float* xb = win + li * PREF_WS + kq;
+            float4v acc2[9];
+#pragma unroll
+            for (int p = 0; p < 9; ++p) acc2[p] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 27; ++s) {
+                const int tap = s / 3, c4 = s - tap * 3, ty = tap / 3, tx = tap - ty * 3;
+#pragma unroll
+                for (int p = 0; p < 9; ++p) {
+                    const int py = p / 3, px = p - py * 3;
+                    acc2[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa2[s], xb[((py + ty) * 5 + px + tx) * 12 + 4 * c4], acc2[p], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();               // every window read is done: the conv2 tile takes the slots' first 144 floats
+#pragma unroll
+            for (int p = 0; p < 9; ++p) {
+                float4v v = acc2[p] + b2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * s2[e];
+                *reinterpret_cast<float4v*>(win + li * PREF_WS + p * 16 + 4 * kq) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- conv3 (two cout tiles) and the heads
+            float4v acc3[2] = {float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int s = 0; s < 36; ++s) {
+                const float bv = xb[(s / 4) * 16 + 4 * (s % 4)];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc3[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa3[i][s], bv, acc3[i], 0, 0, 0);
+            }
+            float4v hd = hb4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float4v v = acc3[i] + b3[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * s3[i][e];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hd = __builtin_amdgcn_mfma_f32_16x16x4f32(hwa[i * 4 + e], v[e], hd, 0, 0, 0);
+            }
+            // D layout: lane (cell li, group kq) holds heads 4 kq .. 4 kq + 3
+            if (i0 + li < n_list && kq < 2) {
+                float* o = a.head + (size_t)lst[i0 + li] * 6 + 4 * kq;
+                *reinterpret_cast<float2*>(o) = make_float2(hd[0], hd[1]);
+                if (kq == 0) *reinterpret_cast<float2*>(o + 2) = make_float2(hd[2], hd[3]);
+            }
+            __builtin_amdgcn_wave_barrier();               // the slots are free for the next trip's windows
         }
     }
 #endif
 }
 
-// ---------------------------------------------------------------- exact f32 re-evaluation of the cells that matter
-// One persistent launch: a block scans a span of 4096 cells' logit differences (written by pnet23), appends the cells
-// with logit1 - logit0 >= logit_thr to a list in LDS (LDS atomics only: a single global counter saturates at ~90
-// appends/us and cost 1.1 ms per batch), then re-evaluates them FOUR per wave (16 lanes per cell: at ~1 % flagged cells
-// a wave that walked its own 64-cell chunk ran mostly empty and serial, 0.98 ms per batch).
-#define PREF_SPAN 4096
-struct PRefArgs {
-    const float* x1; const float* w2; const float* b2; const float* s2; const float* w3; const float* b3; const float* s3;
-    const float* hw; const float* hb; float* head; const float* dl;
-    int B, H1, W1, H3, W3; float logit_thr;               // a cell is re-evaluated iff logit1 - logit0 >= logit_thr
-    int* counter;                                          // optional: accumulated number of re-evaluated cells (diagnostics), or NULL
-};
-
-__global__ __launch_bounds__(256) void pnet_refine_list(PRefArgs a) {
-    __shared__ __attribute__((aligned(16))) float w2s[16 * 164];                        // [cout][10 taps][16 ch] + 4 floats of row padding:
-    __shared__ __attribute__((aligned(16))) float w3s[32 * 164];                        // lanes = couts read 16 B at a 656-B stride, conflict-free
-    __shared__ float cs[16 + 16 + 32 + 32 + 192 + 8];
-    __shared__ __attribute__((aligned(16))) float scr[16][5 * 5 * 12 + 9 * 16];        // per 16-lane group: conv1 window, conv2 activations
-    __shared__ int lst[PREF_SPAN];
-    __shared__ int lcount;
-    const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;
-    for (int e = tid; e < 16 * 40; e += 256) reinterpret_cast<float4v*>(w2s)[(e / 40) * 41 + e % 40] = reinterpret_cast<const float4v*>(a.w2)[e];
-    for (int e = tid; e < 32 * 40; e += 256) reinterpret_cast<float4v*>(w3s)[(e / 40) * 41 + e % 40] = reinterpret_cast<const float4v*>(a.w3)[e];
-    for (int e = tid; e < 16; e += 256) { cs[e] = a.b2[e]; cs[16 + e] = a.s2[e]; }
-    for (int e = tid; e < 32; e += 256) { cs[32 + e] = a.b3[e]; cs[64 + e] = a.s3[e]; }
-    for (int e = tid; e < 192; e += 256) cs[96 + e] = a.hw[e];
-    for (int e = tid; e < 8; e += 256) cs[288 + e] = e < 6 ? a.hb[e] : 0.f;
-    float* xw = scr[grp];
-    float* a2 = xw + 300;
-    const long long ncell = (long long)a.B * a.H3 * a.W3;
-    for (long long span = (long long)blockIdx.x * PREF_SPAN; span < ncell; span += (long long)gridDim.x * PREF_SPAN) {
-    __syncthreads();                                       // the previous span's list has been consumed
-    if (tid == 0) lcount = 0;
-    __syncthreads();
-    for (int k = tid; k < PREF_SPAN; k += 256) {
-        const long long cell = span + k;
-        if (cell < ncell && a.dl[cell] >= a.logit_thr) lst[atomicAdd(&lcount, 1)] = (int)cell;
-    }
-    __syncthreads();
-    const int n_list = lcount;
-    if (a.counter && tid == 0 && n_list) atomicAdd(a.counter, n_list);
-    // every group of the block makes the same number of trips; idle ones work on a clamped cell without storing
-    // conv1 window 5 x 5 x 12 of a cell (always inside the map for a valid conv3 cell): 5 rows of 60 contiguous floats,
-    // fetched into registers ONE TRIP AHEAD so that the global latency hides under the current trip's arithmetic
-    float4v win[5];
-    auto fetch = [&](int i0) {
-        const int i = i0 + grp;
-        const int c = lst[i < n_list ? i : n_list - 1];
-        const int hw3 = a.H3 * a.W3;
-        const int n = c / hw3, r = c - n * hw3, y = r / a.W3, x = r - y * a.W3;
-        const float* src = a.x1 + (((size_t)n * a.H1 + y) * a.W1 + x) * 12 + (l16 < 15 ? l16 : 0) * 4;
-#pragma unroll
-        for (int py = 0; py < 5; ++py) win[py] = *reinterpret_cast<const float4v*>(src + (size_t)py * a.W1 * 12);
-    };
-    if (n_list) fetch(0);
-    for (int i0 = 0; i0 < n_list; i0 += 16) {
-        const int i = i0 + grp;
-        const bool live = i < n_list;
-        const int c = lst[live ? i : n_list - 1];
-        if (l16 < 15) {
-#pragma unroll
-            for (int py = 0; py < 5; ++py) *reinterpret_cast<float4v*>(xw + py * 60 + l16 * 4) = win[py];
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (i0 + 16 < n_list) fetch(i0 + 16);
-        // conv2 at the 3 x 3 positions: lane = cout, 9 plain f32 fma chains over (tap, channel)
-        {
-            float s[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) s[k] = 0.f;
-            for (int tap = 0; tap < 9; ++tap) {
-                const float4v* wp = reinterpret_cast<const float4v*>(w2s + l16 * 164 + tap * 16);
-                const float* xb = xw + ((tap / 3) * 5 + tap % 3) * 12;
-#pragma unroll
-                for (int c4 = 0; c4 < 3; ++c4) {
-                    const float4v w = wp[c4];
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) {
-                        const float4v xv = *reinterpret_cast<const float4v*>(xb + ((k / 3) * 5 + k % 3) * 12 + c4 * 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) s[k] = fmaf(xv[e], w[e], s[k]);
-                    }
-                }
-            }
-            const float b = cs[l16], sl = cs[16 + l16];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) { const float v = s[k] + b; a2[k * 16 + l16] = v > 0.f ? v : v * sl; }
-        }
-        __builtin_amdgcn_wave_barrier();
-        // conv3: couts l16 and l16 + 16; heads: 6 sums over the 32 activations, reduced across the 16 lanes
-        float act[2];
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            const int co = l16 + 16 * h2;
-            float sacc = 0.f;
-            for (int tap = 0; tap < 9; ++tap) {
-                const float4v* ap = reinterpret_cast<const float4v*>(a2 + tap * 16);
-                const float4v* wp = reinterpret_cast<const float4v*>(w3s + co * 164 + tap * 16);
-#pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) {
-                    const float4v av = ap[c4], w = wp[c4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) sacc = fmaf(av[e], w[e], sacc);
-                }
-            }
-            sacc += cs[32 + co];
-            act[h2] = sacc > 0.f ? sacc : sacc * cs[64 + co];
-        }
-        float hs[6];
-#pragma unroll
-        for (int h = 0; h < 6; ++h) {
-            float v = fmaf(act[0], cs[96 + l16 * 6 + h], act[1] * cs[96 + (l16 + 16) * 6 + h]);
-            v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
-            hs[h] = v + cs[288 + h];
-        }
-        if (live && l16 == 0) {
-            float* o = a.head + (size_t)c * 6;
-#pragma unroll
-            for (int h = 0; h < 6; ++h) o[h] = hs[h];
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    }
+// workspace of fr_pnet23_split_f16: [dl: one float per cell][counts: 512 ints][lists: one segment per block]
+static void p23_layout(int B, int H1, int W1, long long& ncell, long long& ntiles, int& grid, int& seg_cap) {
+    const int H3 = H1 - 4, W3 = W1 - 4;
+    ncell = (long long)B * H3 * W3;
+    ntiles = (long long)B * ((W3 + P23_RW - 1) / P23_RW) * ((H3 + P23_RH - 1) / P23_RH);
+    grid = (int)(ntiles < 512 ? ntiles : 512);              // two blocks per CU, persistent over the tiles
+    seg_cap = (int)((ntiles + grid - 1) / (grid > 0 ? grid : 1)) * (P23_RH * P23_RW);
+}
+extern "C" size_t fr_pnet23_workspace_bytes(int B, int H1, int W1) {
+    if (B <= 0 || H1 < 5 || W1 < 5) return 0;
+    long long ncell, ntiles; int grid, seg_cap;
+    p23_layout(B, H1, W1, ncell, ntiles, grid, seg_cap);
+    return (size_t)ncell * 4 + 512 * 4 + (size_t)grid * seg_cap * 4;
 }
 
 extern "C" int fr_pnet23_split_f16(const float* x1, const void* x1s, int B, int H1, int W1, const float* w2, const float* b2,
                                    const float* s2, const float* w3, const float* b3, const float* s3, const float* hw,
-                                   const float* hb, float* head, float refine_logit_thr, int32_t* refined_count,
+                                   const float* hb, float* head, int all_heads, float refine_logit_thr, int32_t* refined_count,
                                    void* workspace, size_t workspace_bytes, fr_stream_t stream) {
     FR_REQUIRE(x1 && x1s && w2 && b2 && s2 && w3 && b3 && s3 && hw && hb && head, "fr_pnet23_split_f16: null pointer");
     FR_REQUIRE((int64_t)B * H1 * W1 * 64 < (1ll << 31), "fr_pnet23_split_f16: the split conv1 map must stay below 2 GiB (got %lld bytes)", (long long)B * H1 * W1 * 64);
     FR_REQUIRE(B > 0 && H1 >= 5 && W1 >= 5, "fr_pnet23_split_f16: the conv1 map must be at least 5x5 (got %dx%d)", H1, W1);
     P23Args a;
-    a.x1 = x1; a.x1s = (const unsigned char*)x1s; a.x1s_bytes = (unsigned)((int64_t)B * H1 * W1 * 64); a.w2 = w2; a.b2 = b2; a.s2 = s2; a.w3 = w3; a.b3 = b3; a.s3 = s3; a.hw = hw; a.hb = hb; a.head = head;
+    a.x1 = x1; a.x1s = (const unsigned char*)x1s; a.x1s_bytes = (unsigned)((int64_t)B * H1 * W1 * 64); a.w2 = w2; a.b2 = b2; a.s2 = s2; a.w3 = w3; a.b3 = b3; a.s3 = s3; a.hw = hw; a.hb = hb; a.head = head; a.all_heads = all_heads;
     a.B = B; a.H1 = H1; a.W1 = W1; a.H3 = H1 - 4; a.W3 = W1 - 4;
     a.tiles_x = (a.W3 + P23_RW - 1) / P23_RW; a.tiles_y = (a.H3 + P23_RH - 1) / P23_RH;
-    const long long ncell = (long long)B * a.H3 * a.W3;
-    FR_REQUIRE(workspace && workspace_bytes >= (size_t)ncell * 4, "fr_pnet23_split_f16: workspace needs %lld bytes", ncell * 4);
+    long long ncell, nt; int grid, seg_cap;
+    p23_layout(B, H1, W1, ncell, nt, grid, seg_cap);
+    FR_REQUIRE(nt < (1ll << 31) && ncell < (1ll << 31), "fr_pnet23_split_f16: too many tiles");
+    const size_t need = fr_pnet23_workspace_bytes(B, H1, W1);
+    FR_REQUIRE(workspace && workspace_bytes >= need, "fr_pnet23_split_f16: workspace needs %zu bytes (fr_pnet23_workspace_bytes)", need);
     a.dl = reinterpret_cast<float*>(workspace);
-    const long long nt = (long long)B * a.tiles_x * a.tiles_y;
-    FR_REQUIRE(nt < (1ll << 31), "fr_pnet23_split_f16: too many tiles");
+    a.counts = reinterpret_cast<int*>(a.dl + ncell);
+    a.list = a.counts + 512;
+    a.seg_cap = seg_cap;
+    a.logit_thr = refine_logit_thr;
     a.ntiles = (int)nt;
-    constexpr size_t lds = (size_t)2 * P23_X1PL + (size_t)2 * P23_X2PL + 30 * 1024 + 104 * 4;       // 81,568 B: two blocks per CU
+    constexpr size_t lds = (size_t)2 * P23_X1PL + (size_t)2 * P23_X2PL + 30 * 1024 + 108 * 4;       // 81,584 B: two blocks per CU
     static FrDevLatch latch;
     if (!fr_raise_lds(reinterpret_cast<const void*>(pnet23_split_f16), lds, latch)) { fr_set_error("fr_pnet23_split_f16: cannot raise dynamic LDS"); return FR_E_LAUNCH; }
     hipStream_t s = fr_stream(stream);
-    int grid = a.ntiles < 512 ? a.ntiles : 512;                     // two blocks per CU, persistent over the tiles
     pnet23_split_f16<<<grid, P23_NT, lds, s>>>(a);
     FR_CHECK_LAUNCH("pnet23_split_f16");
     PRefArgs r;
-    r.x1 = x1; r.w2 = w2; r.b2 = b2; r.s2 = s2; r.w3 = w3; r.b3 = b3; r.s3 = s3; r.hw = hw; r.hb = hb; r.head = head; r.dl = a.dl;
-    r.B = B; r.H1 = H1; r.W1 = W1; r.H3 = a.H3; r.W3 = a.W3; r.logit_thr = refine_logit_thr; r.counter = refined_count;
-    long long g2 = (ncell + PREF_SPAN - 1) / PREF_SPAN;
-    if (g2 > 512) g2 = 512;
-    pnet_refine_list<<<(int)g2, 256, 0, s>>>(r);
-    FR_CHECK_LAUNCH("pnet_refine_list");
+    r.x1 = x1; r.w2 = w2; r.b2 = b2; r.s2 = s2; r.w3 = w3; r.b3 = b3; r.s3 = s3; r.hw = hw; r.hb = hb; r.head = head;
+    r.list = a.list; r.counts = a.counts; r.seg_cap = seg_cap;
+    r.B = B; r.H1 = H1; r.W1 = W1; r.H3 = a.H3; r.W3 = a.W3; r.counter = refined_count;
+    pnet_refine_mfma<<<grid, 256, 0, s>>>(r);              // block b takes the list of pnet23's block b
+    FR_CHECK_LAUNCH("pnet_refine_mfma");
     return FR_OK;
 }

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void crop_conv1_kernel(RoArgs a) {
                     const float p00 = E ? (src0 ? f0[ch] : 0.f) : f0[ch], p10 = E ? (src0 ? f1[ch] : 0.f) : f1[ch];
                     const float p01 = E ? (src1 == 2 ? s0[ch] : (src1 == 1 ? f0[ch] : 0.f)) : s0[ch];
                     const float p11 = E ? (src1 == 2 ? s1[ch] : (src1 == 1 ? f1[ch] : 0.f)) : s1[ch];
-                    v[ch] = (bilerp_r(p00, p01, p10, p11, wx, wy) - 127.5f) * 0.0078125f;
+                    v[ch] = __builtin_fmaf(bilerp_r(p00, p01, p10, p11, wx, wy), 0.0078125f, -0.99609375f);      // == (s - 127.5) * 2^-7 bit for bit (pnet_conv1.hip)
                 }
             }
             xin[t * 3 + 0] = v[0]; xin[t * 3 + 1] = v[1]; xin[t * 3 + 2] = v[2];

@@ -152,6 +152,7 @@ class MTCNNHIP:
             w2p, p["conv2.bias"], p["prelu2.weight"], w3p, p["conv3.bias"], p["prelu3.weight"], hw.t().contiguous(), hb))
         self.refine_margin = 2e-3           # in logit units, ~200x the split-precision error
         self.refined_cells = None           # optional device int32[1]: cells re-evaluated exactly (diagnostics)
+        self.p23_all_heads = False          # True: the fused kernel also writes the approximate heads of the cells it rules out
         # first R-/O-Net layer fused with the crop (csrc/ro_conv1.hip): weights as [k = (kh, kw, channel)][cout]
         self.fused_crop = True
         self._rc1 = tuple(t.to(torch.float32).contiguous().to(d) for t in (
@@ -238,9 +239,9 @@ class MTCNNHIP:
             x, h, w = self._dconv(None, self.p1, N, hs, ws, frames=frames, y_split=xs)
             t0 = self.thresholds[0]
             head = self._f32(N, h - 4, w - 4, 6)
-            ws = torch.empty(N * (h - 4) * (w - 4), dtype=torch.float32, device=self.device)
+            ws = torch.empty(self.lib.fr_pnet23_workspace_bytes(N, h, w) // 4, dtype=torch.float32, device=self.device)
             self.lib.fr_pnet23_split_f16(_lib.ptr(x), _lib.ptr(xs), N, h, w, *[_lib.ptr(t) for t in self._p23], _lib.ptr(head),
-                                         math.log(t0 / (1.0 - t0)) - self.refine_margin, _lib.ptr(self.refined_cells),
+                                         1 if (self.p23_all_heads or trace is not None) else 0, math.log(t0 / (1.0 - t0)) - self.refine_margin, _lib.ptr(self.refined_cells),
                                          _lib.ptr(ws), ws.numel() * 4, self._s)
             self._dl = (ws, math.log(t0 / (1.0 - t0)) - self.refine_margin)     # pre-filter for fr_pnet_candidates
             return head, h - 4, w - 4

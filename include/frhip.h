@@ -324,11 +324,15 @@ int fr_crop_conv1_f32(int net, const uint8_t* frames, int nframes, int H, int W,
  * f32 [B,H1,W1,12]; w2 [16][10][16] / w3 [32][10][16]: (cout, tap, channel) with tap 9 and unused channels zero;
  * x1s: the same map as split f16 (y_split of layer 0), streamed into LDS by LDS-DMA.
  * b/s: bias and PReLU slope; hw [32][6], hb [6]: conv4_1|conv4_2.  head: f32 [B,H1-4,W1-4,6].
+ * all_heads: 0 = only the rows of re-evaluated cells are written (all fr_pnet_candidates reads when it is given the
+ * workspace as `dl` and refine_logit_thr as `dl_min`); 1 = the approximate heads of every other cell too (tests, traces).
  * refined_count (optional device i32, accumulated): number of re-evaluated cells.
- * workspace: B*(H1-4)*(W1-4) * 4 bytes (logit differences, the re-evaluation pass scans them). */
+ * workspace: fr_pnet23_workspace_bytes(B, H1, W1) bytes; its first B*(H1-4)*(W1-4) floats are the logit differences
+ * (the `dl` argument of fr_pnet_candidates), behind them the per-block lists of the cells the exact pass re-evaluates. */
+size_t fr_pnet23_workspace_bytes(int B, int H1, int W1);
 int fr_pnet23_split_f16(const float* x1, const void* x1s, int B, int H1, int W1, const float* w2, const float* b2, const float* s2,
                         const float* w3, const float* b3, const float* s3, const float* hw, const float* hb,
-                        float* head, float refine_logit_thr, int32_t* refined_count, void* workspace,
+                        float* head, int all_heads, float refine_logit_thr, int32_t* refined_count, void* workspace,
                         size_t workspace_bytes, fr_stream_t stream);
 /* max pool, ceil mode, f32 NHWC */
 int fr_maxpool_f32(const float* x, float* y, int B, int H, int W, int C, int k, int stride,

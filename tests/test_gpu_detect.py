@@ -208,6 +208,7 @@ def test_fused_split_f16_pnet_equals_f32_pnet():
     worst = 0.0
     for hw, seed in (((240, 320), 21), ((480, 640), 0), ((1080, 1920), 31), ((96, 128), 3)):
         fr = torch.from_numpy(np.ascontiguousarray(np.stack([synth_frame(hw[0], hw[1], seed + k) for k in range(2)]))).cuda()
+        fused.p23_all_heads = True          # the level-by-level comparison reads the heads of EVERY cell
         for s in pyramid_scales(*hw):
             with torch.cuda.device("cuda:0"):
                 fused._s = plain._s = torch.cuda.current_stream().cuda_stream
@@ -220,8 +221,9 @@ def test_fused_split_f16_pnet_equals_f32_pnet():
             keep_f = (hf[..., 1] - hf[..., 0]) >= np.log(1.5)
             assert torch.equal(keep_p, keep_f)
             if keep_p.any():
-                assert float(d[keep_p].max()) < 2e-6, float(d[keep_p].max())
+                assert float(d[keep_p].max()) == 0.0, float(d[keep_p].max())     # the exact pass runs the all-f32 path's own MFMA chains
             total += keep_p.numel(); kept += int(keep_p.sum())
+        fused.p23_all_heads = False         # the product setting: only the re-evaluated cells' heads are written
         a = fused.detect_batch(fr); b = plain.detect_batch(fr)
         assert torch.equal(a[3], b[3])
         for f in range(fr.shape[0]):
