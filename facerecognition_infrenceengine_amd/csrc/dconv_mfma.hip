@@ -628,9 +628,9 @@ extern "C" int fr_dconv_mfma_f32(int layer, const float* x, const float* w, cons
         case 11: FR_REQUIRE(H == 11 && W == 11, "R2 expects 11x11");                        // conv2 + 3x3/s2 pool -> 4x4
                  rc = launch_dc<28, 48, 3, 3, 9, 9, 2, 3, 1, 3, 2, 3, 8, 8, 0, 1, 0>(a, s); break;
         case 12: FR_REQUIRE(H == 4 && W == 4, "R3 expects 4x4");
-                 rc = launch_dc<48, 64, 2, 2, 3, 3, 8, 4, 2, 1, 0, 2, 3, 3, 0, 1, 0>(a, s); break;
+                 rc = launch_dc<48, 64, 2, 2, 3, 3, 16, 4, 2, 1, 0, 2, 3, 3, 0, 1, 0>(a, s); break;
         case 13: FR_REQUIRE(H == 3 && W == 3, "R4 expects 3x3");
-                 rc = launch_dc<64, 128, 3, 3, 1, 1, 16, 4, 4, 1, 0, 2, 1, 1, 0, 1, 0>(a, s); break;      // dense4
+                 rc = launch_dc<64, 128, 3, 3, 1, 1, 32, 4, 4, 1, 0, 2, 1, 1, 0, 1, 0>(a, s); break;      // dense4
         case 14: FR_REQUIRE(H == 1 && W == 1, "R5 expects 1x1");
                  rc = launch_dc<128, 6, 1, 1, 1, 1, 64, 1, 1, 1, 0, 2, 1, 1, 0, 1, 0>(a, s); break;       // dense5_1|5_2
         case 20: FR_REQUIRE(H == 48 && W == 48, "O1 expects 48x48");                        // conv1 + 3x3/s2 pool -> 23x23
@@ -640,7 +640,7 @@ extern "C" int fr_dconv_mfma_f32(int layer, const float* x, const float* w, cons
         case 22: FR_REQUIRE(H == 10 && W == 10, "O3 expects 10x10");                        // conv3 + 2x2/s2 pool -> 4x4
                  rc = launch_dc<64, 64, 3, 3, 8, 8, 1, 4, 1, 1, 2, 2, 8, 8, 0, 1, 0>(a, s); break;
         case 23: FR_REQUIRE(H == 4 && W == 4, "O4 expects 4x4");
-                 rc = launch_dc<64, 128, 2, 2, 3, 3, 8, 4, 2, 1, 0, 2, 3, 3, 0, 1, 0>(a, s); break;
+                 rc = launch_dc<64, 128, 2, 2, 3, 3, 16, 4, 2, 1, 0, 2, 3, 3, 0, 1, 0>(a, s); break;
         case 24: FR_REQUIRE(H == 3 && W == 3, "O5 expects 3x3");
                  rc = launch_dc<128, 256, 3, 3, 1, 1, 16, 4, 4, 1, 0, 2, 1, 1, 0, 1, 0>(a, s); break;     // dense5
         case 25: FR_REQUIRE(H == 1 && W == 1, "O6 expects 1x1");
