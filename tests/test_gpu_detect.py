@@ -236,6 +236,43 @@ def test_fused_split_f16_pnet_equals_f32_pnet():
     assert kept >= 100 and refined >= kept
 
 
+def test_fused_pnet_exact_pass_with_every_cell_on_its_work_list():
+    """The exact pass of the fused P-Net takes its cells from per-block lists the split-precision kernel fills
+    (csrc/pnet_fused.hip).  With a face threshold near zero (almost) EVERY cell is on a list: full segments, many trips per
+    wave, ragged tiles at the map borders, several frames.  Every listed cell must carry the all-f32 path's head values
+    bit for bit, with and without the approximate head rows of the others."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import synth_frame
+    from facerecognition_infrenceengine_amd import weights
+    from facerecognition_infrenceengine_amd.mtcnn import MTCNNHIP, pyramid_scales
+    st = weights.synth_mtcnn_states(seed=77)
+    thr = (1e-4, 0.7, 0.7)
+    fused = MTCNNHIP(*st, device="cuda:0", fused_pnet=True, thresholds=thr)
+    plain = MTCNNHIP(*st, device="cuda:0", fused_pnet=False, thresholds=thr)
+    fused.refined_cells = torch.zeros(1, dtype=torch.int32, device="cuda")
+    logit_thr = float(np.log(thr[0] / (1.0 - thr[0])))
+    listed = total = 0
+    for hw, nfr in (((131, 197), 3), ((480, 640), 2)):
+        fr = torch.from_numpy(np.ascontiguousarray(np.stack([synth_frame(hw[0], hw[1], 50 + k) for k in range(nfr)]))).cuda()
+        for s in pyramid_scales(*hw)[:4]:
+            for all_heads in (True, False):
+                fused.p23_all_heads = all_heads
+                with torch.cuda.device("cuda:0"):
+                    fused._s = plain._s = torch.cuda.current_stream().cuda_stream
+                    hf, h1, w1 = fused.pnet_level(fr, s)
+                    dl = fused._dl[0][:fr.shape[0] * h1 * w1].reshape(fr.shape[0], h1, w1).clone()
+                    hp, h2, w2 = plain.pnet_level(fr, s)
+                torch.cuda.synchronize()
+                on_list = dl >= logit_thr - fused.refine_margin
+                assert torch.equal(hf[on_list], hp[on_list])
+                # whatever the split-precision pass ruled out is below the threshold in the f32 path too
+                assert bool(((hp[..., 1] - hp[..., 0])[~on_list] < logit_thr).all())
+            listed += int(on_list.sum()); total += on_list.numel()
+    assert listed > 0.9 * total, (listed, total)
+    assert int(fused.refined_cells[0]) == 2 * listed
+
+
 @pytest.mark.parametrize("negative_slopes", [False, True])
 def test_pnet_conv1_kernel_vs_oracle_and_16x16x4_form(negative_slopes):
     """P-Net conv1 (+ pyramid resize, PReLU, 2x2 ceil pool) runs as its own 4x4x1-MFMA kernel (csrc/pnet_conv1.hip).
