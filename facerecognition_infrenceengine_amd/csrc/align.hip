@@ -9,6 +9,7 @@ __constant__ double ARC_DST[5][2] = {{38.2946, 51.6963}, {73.5318, 51.5014}, {56
                                      {41.5493, 92.3655}, {70.7299, 92.2041}};
 
 typedef unsigned long long u64_unaligned_w __attribute__((aligned(1)));
+#define WARP_NB 7
 __global__ __launch_bounds__(256) void warp_affine_5pt(const uint8_t* __restrict__ frames, int nframes, int H, int W,
                                                        const float* __restrict__ kps,
                                                        const int32_t* __restrict__ frame_idx,
@@ -16,7 +17,8 @@ __global__ __launch_bounds__(256) void warp_affine_5pt(const uint8_t* __restrict
                                                        const int32_t* __restrict__ slot_counts, int slot_cap, int size,
                                                        half_t* __restrict__ out, uint8_t* __restrict__ out_u8,
                                                        float* __restrict__ M_out) {
-    const int f = blockIdx.x;
+    // WARP_NB blocks per face, one band of rows each: a single face (the single-frame path) was ONE block's 45 us
+    const int f = blockIdx.x / WARP_NB, band = blockIdx.x - f * WARP_NB;
     // validity: compact list (f < *count), or fixed per-frame slots (slot f = frame*cap + j valid iff j < counts[frame])
     const bool valid = slot_counts ? ((f % slot_cap) < slot_counts[f / slot_cap]) : (count == nullptr || f < *count);
     __shared__ double inv[6];
@@ -36,7 +38,7 @@ __global__ __launch_bounds__(256) void warp_affine_5pt(const uint8_t* __restrict
         }
         const double a = num_a / var, b = num_b / var;
         const double tx = mdx - (a * msx - b * msy), ty = mdy - (b * msx + a * msy);
-        if (M_out) {
+        if (M_out && band == 0) {
             float* m = M_out + (int64_t)f * 6;
             m[0] = (float)a; m[1] = (float)-b; m[2] = (float)tx; m[3] = (float)b; m[4] = (float)a; m[5] = (float)ty;
         }
@@ -50,7 +52,9 @@ __global__ __launch_bounds__(256) void warp_affine_5pt(const uint8_t* __restrict
     const uint8_t* fr = frames + (int64_t)fidx * H * W * 3;
     const long long lim = fidx == nframes - 1 ? (long long)H * W * 3 - 8 : (1ll << 62);     // last frame: never read past the buffer
     half_t* o = out + (int64_t)f * size * size * 8;
-    for (int t = threadIdx.x; t < size * size; t += 256) {
+    const int rows = (size + WARP_NB - 1) / WARP_NB;
+    const int t_end = min((band + 1) * rows, size) * size;
+    for (int t = band * rows * size + threadIdx.x; t < t_end; t += 256) {
         const int y = t / size, x = t - y * size;
         float rgb[3] = {0.f, 0.f, 0.f};
         unsigned char u[3] = {0, 0, 0};
@@ -114,7 +118,7 @@ extern "C" int fr_warp_affine_5pt(const uint8_t* frames, int nframes, int H, int
     if (F <= 0) return FR_OK;
     FR_REQUIRE(frames && kps && frame_idx && out_f16_nhwc8, "fr_warp_affine_5pt: null pointer");
     FR_REQUIRE(nframes > 0 && H > 0 && W > 0 && size > 0, "fr_warp_affine_5pt: bad size");
-    warp_affine_5pt<<<F, 256, 0, fr_stream(stream)>>>(frames, nframes, H, W, kps, frame_idx, count, nullptr, 1, size,
+    warp_affine_5pt<<<F * WARP_NB, 256, 0, fr_stream(stream)>>>(frames, nframes, H, W, kps, frame_idx, count, nullptr, 1, size,
                                                       reinterpret_cast<half_t*>(out_f16_nhwc8), out_u8_bgr, M_out);
     FR_CHECK_LAUNCH("warp_affine_5pt");
     return FR_OK;
@@ -127,7 +131,7 @@ extern "C" int fr_warp_affine_5pt_slots(const uint8_t* frames, int nframes, int 
                                         fr_stream_t stream) {
     FR_REQUIRE(frames && kps && counts && out_f16_nhwc8 && nframes > 0 && cap > 0 && H > 0 && W > 0 && size > 0,
                "fr_warp_affine_5pt_slots: bad argument");
-    warp_affine_5pt<<<nframes * cap, 256, 0, fr_stream(stream)>>>(frames, nframes, H, W, kps, nullptr, nullptr, counts, cap, size,
+    warp_affine_5pt<<<nframes * cap * WARP_NB, 256, 0, fr_stream(stream)>>>(frames, nframes, H, W, kps, nullptr, nullptr, counts, cap, size,
                                                                   reinterpret_cast<half_t*>(out_f16_nhwc8), nullptr, nullptr);
     FR_CHECK_LAUNCH("warp_affine_5pt");
     return FR_OK;

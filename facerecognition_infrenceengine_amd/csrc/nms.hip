@@ -35,8 +35,12 @@ __global__ __launch_bounds__(NMS_T) void sort_nms(const float* __restrict__ boxe
         int64_t seg = seg_major ? (int64_t)s * L + l : (int64_t)l * nseg + s;
         return seg * seg_cap + j;
     };
-    int myvalid = 0;
-    for (int i = tid; i < NP; i += NMS_T) {
+    // Keys of the VALID entries only, compacted (the order they land in does not matter: a key carries its entry's
+    // index as the tie-break), then a bitonic sort of the next power of two above their number - not of the lists'
+    // capacity: a single frame's merged per-level lists (20 480 slots, a few hundred entries) sorted 2 048 + 4 096 keys in
+    // 51 + 77 us.  One LDS atomic per wave and pass.
+    for (int i0 = 0; i0 < NP; i0 += NMS_T) {
+        const int i = i0 + tid;
         unsigned long long k = 0ull;
         if (i < ntot) {
             int s = i / seg_cap, j = i - s * seg_cap;
@@ -44,17 +48,28 @@ __global__ __launch_bounds__(NMS_T) void sort_nms(const float* __restrict__ boxe
             if (j < counts[seg]) {
                 unsigned sb_ = __float_as_uint(scores[seg * seg_cap + j]);
                 k = ((unsigned long long)sb_ << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
-                ++myvalid;
             }
         }
-        key[i] = k;
+        // a valid key is never 0: its low word is 0xFFFFFFFF - i with i < 4096
+        const unsigned long long bal = __ballot(k != 0ull);
+        if (bal) {
+            const int ln = tid & 63, first = (int)__builtin_ctzll(bal);
+            int base = 0;
+            if (ln == first) base = atomicAdd(&nvalid_s, (int)__builtin_popcountll(bal));
+            base = __shfl(base, first, 64);
+            if (k != 0ull) key[base + (int)__builtin_popcountll(bal & ((1ull << ln) - 1ull))] = k;
+        }
     }
-    if (myvalid) atomicAdd(&nvalid_s, myvalid);
+    __syncthreads();
+    const int nv = nvalid_s;
+    int NS = 1;
+    while (NS < nv) NS <<= 1;
+    for (int i = nv + tid; i < NS; i += NMS_T) key[i] = 0ull;
     __syncthreads();
     // bitonic sort, descending
-    for (int k = 2; k <= NP; k <<= 1) {
+    for (int k = 2; k <= NS; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < NP / 2; t += NMS_T) {
+            for (int t = tid; t < NS / 2; t += NMS_T) {
                 int i = 2 * t - (t & (j - 1));        // index with bit j clear
                 int p = i + j;
                 bool desc = (i & k) == 0;
