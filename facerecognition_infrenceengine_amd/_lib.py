@@ -64,6 +64,7 @@ SIGNATURES = {
     "fr_mean_rows_f32": (_I, [_P, _I, _I, _P, _P]),
     "fr_conv_nhwc_f16": (_I, [C.POINTER(ConvArgs), _P]),
     "fr_conv_sequence": (_I, [C.POINTER(ConvStep), _I, _P]),
+    "fr_conv_inblock_f16": (_I, [C.POINTER(ConvArgs), _P]),
     "fr_conv_nhwc_f8": (_I, [C.POINTER(ConvF8Args), _P]),
     "fr_quantize_f16_f8": (_I, [_P, _P, _L, _F, _P]),
     "fr_quantize_f16_f8_centred": (_I, [_P, _P, _L, _I, _P, _F, _P]),

@@ -556,6 +556,8 @@ extern "C" int fr_conv_sequence(const fr_conv_step* steps, int nsteps, fr_stream
             if (rc == FR_OK)
                 rc = fr_conv_splitk_epilogue(a.out_f32_partial, a.splitk, a.B * a.Ho * a.Wo, a.Cout, a.Ho, a.Wo, a.bias,
                                              a.bias_mode, a.slope, a.residual, a.y, stream);
+        } else if (st.kind == 2) {
+            rc = fr_conv_inblock_f16(&st.args, stream);
         } else {
             FR_REQUIRE(false, "fr_conv_sequence: step %d: unknown kind %d", i, st.kind);
         }

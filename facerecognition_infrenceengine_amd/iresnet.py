@@ -28,6 +28,9 @@ BN_EPS = 1e-5
 FC_SPLITK = 28
 # up to this many faces the 3x3 convs run split along K (see IResNetHIP._small_batch_splitk)
 SMALL_BATCH = 48      # measured crossover: 32 faces 2.7 vs 3.3 ms, 64 faces 4.6 vs 3.7 ms
+# up to this many faces the 3x3 / stride-1 convs with >= 128 input channels run split along K INSIDE a workgroup, one launch
+# per conv (fr_conv_inblock_f16) instead of the partials launch + fr_conv_splitk_epilogue (see IResNetHIP._inblock)
+INBLOCK_BATCH = 2
 # up to this many faces (single frames) every K slice is at most 3 K steps long: a slice's steps are dependent HBM
 # round trips (the weights are cold: 130 MB per forward), so a launch takes ~1.2 us per step + ~3 us
 LOW_BATCH = 8
@@ -195,11 +198,13 @@ class IResNetHIP:
     f16 [B,112,112,8] (RGB in channels 0..2, (x-127.5)/127.5, rest zero) produced by
     ``fr_warp_affine_5pt`` and returns (embedding, normed_embedding) f32 [B,512] on device."""
 
-    def __init__(self, state, arch="r100", device="cuda:0", max_chunk=256, small_batch=SMALL_BATCH, low_batch=LOW_BATCH):
+    def __init__(self, state, arch="r100", device="cuda:0", max_chunk=256, small_batch=SMALL_BATCH, low_batch=LOW_BATCH,
+                 inblock_batch=INBLOCK_BATCH):
         """``small_batch`` / ``low_batch``: batch-size modes of the split-K single-frame path (module constants above;
         arguments, not environment variables: the product reads no environment)."""
         _lib.require_gpu()
         self.small_batch, self.low_batch = int(small_batch), int(low_batch)
+        self.inblock_batch = int(inblock_batch)
         self.lib = _lib.load()
         self.device = torch.device(device)
         self.arch = arch
@@ -543,9 +548,24 @@ class IResNetHIP:
             return -(-nk // 3)
         return min(8, nk // 9)
 
+    def _inblock(self, c, B):
+        """One or two faces (single frames): a 3x3 / stride-1 conv with >= 128 input channels is ONE launch that splits K
+        among the sixteen waves of a workgroup (csrc/conv_inblock.hip) - the split-K form is two launches at their
+        latency floor, 89 times per forward.  A mode of its own: inside it a face's embedding does not depend on its
+        batch mate, against the other modes it differs by f32 summation order."""
+        return (B <= self.inblock_batch and c.k == 3 and c.stride == 1 and c.pad == 1 and c.cin % 32 == 0
+                and 128 <= c.cin <= 512 and c.cout % 32 == 0 and isinstance(c, _Conv))
+
     def _conv(self, x, c, B, H, W, residual=None, partial=None, splitk=1, y=None, x2=None):
         Ho = (H + 2 * c.pad - c.k) // c.stride + 1
         Wo = (W + 2 * c.pad - c.k) // c.stride + 1
+        if partial is None and x2 is None and self.profile is None and self._inblock(c, B):
+            if y is None:
+                y = torch.empty((B, Ho, Wo, c.cout), dtype=torch.float16, device=self.device)
+            a = _lib.ConvArgs(_lib.ptr(x), _lib.ptr(c.w), _lib.ptr(y), _lib.ptr(c.bias), _lib.ptr(c.slope), _lib.ptr(residual), None,
+                              B, H, W, c.cin, c.cout, c.k, c.k, c.stride, c.pad, Ho, Wo, c.bias_mode, 1, None, 0)
+            self.lib.fr_conv_inblock_f16(ctypes.byref(a), _lib.stream_ptr())
+            return y, Ho, Wo
         sk = self._small_batch_splitk(c, B) if partial is None and self.profile is None else 1
         if sk > 1:
             if y is None:
@@ -667,6 +687,9 @@ class IResNetHIP:
             nonlocal part_floats
             Ho = (H + 2 * c.pad - c.k) // c.stride + 1
             Wo = (W + 2 * c.pad - c.k) // c.stride + 1
+            if x2 is None and self._inblock(c, B):
+                steps.append((2, c, x, y, residual, H, W, Ho, Wo, 1, x2))
+                return Ho, Wo
             sk = self._small_batch_splitk(c, B)
             if sk > 1:
                 part_floats = max(part_floats, sk * B * Ho * Wo * c.cout)
@@ -699,7 +722,7 @@ class IResNetHIP:
         for st, (kind, c, x, y, residual, Hi, Wi, Ho, Wo, sk, x2) in zip(arr, steps):
             st.kind = kind
             st.args = _lib.ConvArgs(_lib.ptr(x), _lib.ptr(c.w), _lib.ptr(y), _lib.ptr(c.bias), _lib.ptr(c.slope),
-                                    _lib.ptr(residual), _lib.ptr(partial) if kind else None, B, Hi, Wi, c.cin, c.cout,
+                                    _lib.ptr(residual), _lib.ptr(partial) if kind == 1 else None, B, Hi, Wi, c.cin, c.cout,
                                     c.k, c.k, c.stride, c.pad, Ho, Wo, c.bias_mode, sk, _lib.ptr(x2), c.c2 if x2 is not None else 0)
         plan = self._plans[key] = (arr, len(steps), view(h, H, W, hc), bufs, partial)
         return plan

@@ -237,11 +237,18 @@ int fr_gptq_round_e4m3(const double* W, const double* U, const float* sw, float*
 int fr_conv_splitk_epilogue(const float* partial, int splitk, int M, int Cout, int Ho, int Wo,
                             const float* bias, int bias_mode, const float* slope, const void* residual,
                             void* y, fr_stream_t stream);
+/* 3x3 / stride 1 / pad 1 conv of a one- or two-face forward (single frames; same reference site, infrenceServer.py:528),
+ * split along K INSIDE a workgroup: sixteen waves share one 16-pixel x 32-cout output tile, a sixteenth of K each, partials
+ * summed through LDS in wave order, then the fused epilogue of fr_conv_nhwc_f16 ((border-class) bias -> PReLU -> + residual
+ * -> one rounding to f16) - ONE launch where the split-K mode of fr_conv_nhwc_f16 + fr_conv_splitk_epilogue are two
+ * (conv_inblock.hip).  Takes fr_conv_args with KH = KW = 3, stride 1, pad 1, Cin % 32 == 0, Cin <= 512, Cout % 32 == 0,
+ * x2 / out_f32_partial NULL; splitk is ignored.  Differs from the other modes by f32 summation order only. */
+int fr_conv_inblock_f16(const fr_conv_args* args, fr_stream_t stream);
 /* A prepared run of convs in ONE call (single frames are launch-bound from an interpreted host: ~100 convs of a few
  * microseconds each).  Step kind 0: fr_conv_nhwc_f16(args).  Kind 1: the small-batch split-K form of the conv that
  * `args` describes as a whole (x, w, y, bias, bias_mode, slope, residual, splitk > 1, out_f32_partial = scratch of
- * splitk * M * Cout floats): the partials launch followed by fr_conv_splitk_epilogue into args.y.  Same kernels, same
- * order, same bits as the individual calls; stops at the first failing step. */
+ * splitk * M * Cout floats): the partials launch followed by fr_conv_splitk_epilogue into args.y.  Kind 2:
+ * fr_conv_inblock_f16(args).  Same kernels, same order, same bits as the individual calls; stops at the first failing step. */
 typedef struct {
     int kind;
     fr_conv_args args;

@@ -18,7 +18,7 @@ def nchw_to_nhwc8(x):
     return out.cuda()
 
 
-def _conv_case(lib, B, H, W, Cin, Cout, k, stride, pad, bias_mode, slope, residual, seed):
+def _conv_case(lib, B, H, W, Cin, Cout, k, stride, pad, bias_mode, slope, residual, seed, entry="fr_conv_nhwc_f16"):
     from facerecognition_infrenceengine_amd import _lib
     g = torch.Generator().manual_seed(seed)
     x = torch.randn((B, Cin, H, W), generator=g)
@@ -50,7 +50,7 @@ def _conv_case(lib, B, H, W, Cin, Cout, k, stride, pad, bias_mode, slope, residu
     bd = bias.cuda(); sd = sl.cuda() if sl is not None else None; rd = res.cuda() if res is not None else None
     a = _lib.ConvArgs(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), _lib.ptr(bd), _lib.ptr(sd), _lib.ptr(rd), None,
                       B, H, W, Cin, Cout, k, k, stride, pad, Ho, Wo, bias_mode, 1)
-    lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
+    getattr(lib, entry)(ctypes.byref(a), _lib.stream_ptr())
     torch.cuda.synchronize()
     got = y.float().cpu().permute(0, 3, 1, 2)
     err = (got - ref).abs().max().item()
@@ -76,6 +76,65 @@ def _conv_case(lib, B, H, W, Cin, Cout, k, stride, pad, bias_mode, slope, residu
 ])
 def test_conv_layer_vs_torch(lib, case):
     _conv_case(lib, *case, seed=hash(case) & 0xffff)
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, bias_mode, slope, residual: the single-frame form of the 3x3 / s1 body convs (csrc/conv_inblock.hip)
+    (1, 14, 14, 256, 256, 1, True, False),       # 72 K steps: waves with 5 and with 4; 196 pixels = 12 tiles + 4 pixels
+    (1, 14, 14, 256, 256, 0, False, True),
+    (2, 28, 28, 128, 128, 1, True, False),       # 36 K steps: 3 and 2 per wave
+    (2, 28, 28, 128, 128, 0, False, True),
+    (1, 7, 7, 512, 512, 1, True, True),          # 144 K steps: 9 per wave (the ring of five wraps), 49 pixels = 3 tiles + 1
+    (2, 7, 7, 512, 512, 0, False, True),
+    (1, 28, 28, 128, 256, 1, True, False),       # Cout != Cin
+    (3, 5, 9, 160, 96, 1, True, True),           # odd image, 45 K steps, three cout tiles, a tile across two images
+    (1, 2, 2, 128, 32, 1, False, False),         # every pixel a corner, one cout tile
+])
+def test_inblock_conv_vs_torch(lib, case):
+    B, H, W, Cin, Cout, bias_mode, slope, residual = case
+    _conv_case(lib, B, H, W, Cin, Cout, 3, 1, 1, bias_mode, slope, residual, seed=hash(case) & 0xffff, entry="fr_conv_inblock_f16")
+
+
+def test_inblock_conv_refuses_what_it_cannot_compute(lib):
+    from facerecognition_infrenceengine_amd import _lib
+    x = torch.zeros((1, 8, 8, 64), dtype=torch.float16, device="cuda")
+    w = torch.zeros((64, 9 * 64), dtype=torch.float16, device="cuda")
+    y = torch.empty((1, 8, 8, 64), dtype=torch.float16, device="cuda")
+    def args(**kw):
+        d = dict(B=1, H=8, W=8, Cin=64, Cout=64, k=3, stride=1, pad=1, Ho=8, Wo=8)
+        d.update(kw)
+        return _lib.ConvArgs(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), None, None, None, None, d["B"], d["H"], d["W"], d["Cin"], d["Cout"],
+                             d["k"], d["k"], d["stride"], d["pad"], d["Ho"], d["Wo"], 0, 1)
+    for bad in (dict(stride=2, Ho=4, Wo=4), dict(k=1, pad=0), dict(Cin=48), dict(Cout=48), dict(Cin=1024)):
+        with pytest.raises(_lib.FrError):
+            lib.fr_conv_inblock_f16(ctypes.byref(args(**bad)), _lib.stream_ptr())
+    lib.fr_conv_inblock_f16(ctypes.byref(args()), _lib.stream_ptr())       # Cin = 64 is computable (the engine does not route it here)
+    torch.cuda.synchronize()
+    assert float(y.float().abs().max()) == 0.0
+
+
+def test_inblock_mode_on_r100_vs_split_k_mode(r100):
+    """One- and two-face forwards take the in-block split-K convs (IResNetHIP.inblock_batch); the same faces through the
+    split-K + epilogue mode (inblock_batch = 0) differ by f32 summation order only, and a face's embedding does not depend
+    on its batch mate inside the mode."""
+    g = torch.Generator().manual_seed(5)
+    x = nchw_to_nhwc8(torch.randn((2, 3, 112, 112), generator=g))
+    assert r100.inblock_batch >= 2
+    e2, n2 = r100.forward(x)
+    e1, n1 = r100.forward(x[:1].contiguous())
+    saved = r100.inblock_batch
+    try:
+        r100.inblock_batch = 0
+        r100.release_plans()
+        e0, n0 = r100.forward(x)
+    finally:
+        r100.inblock_batch = saved
+        r100.release_plans()
+    torch.cuda.synchronize()
+    assert torch.equal(e2[:1], e1)
+    cos = (n2 * n0).sum(1)
+    assert float((1 - cos).max()) < 1e-5, cos
+    assert not torch.equal(e2, e0)          # a different kernel did run
 
 
 @pytest.mark.parametrize("B,H,Cmid,C2,Cout,splitk", [(2, 28, 128, 64, 128, 1), (3, 56, 64, 64, 64, 1), (1, 14, 256, 128, 256, 1),
@@ -218,9 +277,13 @@ def test_r100_batch_independence(r100):
     g = torch.Generator().manual_seed(5)
     x = torch.rand((5, 3, 112, 112), generator=g) * 2 - 1
     xa = nchw_to_nhwc8(x)
-    e_all, _ = r100.forward(xa)
-    e_one, _ = r100.forward(xa[3:4].contiguous())
-    assert torch.equal(e_all[3:4], e_one)
+    e_all, n_all = r100.forward(xa)
+    e_three, _ = r100.forward(xa[2:5].contiguous())      # the same batch-size mode (3 .. 8 faces): bit for bit
+    assert torch.equal(e_all[2:5], e_three)
+    e_two, _ = r100.forward(xa[3:5].contiguous())        # the one- / two-face mode (in-block split-K convs): bit for bit inside it,
+    e_one, n_one = r100.forward(xa[3:4].contiguous())    # f32 summation order against the other modes
+    assert torch.equal(e_two[:1], e_one)
+    assert float(1 - (n_all[3:4] * n_one).sum()) < 1e-5
 
 
 def test_prepared_sequence_equals_launch_by_launch(r100, monkeypatch):
