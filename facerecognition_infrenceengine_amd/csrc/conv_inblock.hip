@@ -1,4 +1,4 @@
-// 3x3 / stride 1 / pad 1 convs of a ONE- or TWO-face forward (the embed half of a single-frame FaceAnalysis.get,
+// 3x3 / stride 1 / pad 1 convs of a forward of ONE to FOUR faces (the embed half of a single-frame FaceAnalysis.get,
 // /root/reference/infrenceServer.py:528): split along K INSIDE a workgroup, one launch per conv.
 //
 // Why: a single face's 14x14x256 conv is 231 MFLOP over 72 K steps; cut into slices that run side by side on different
@@ -26,11 +26,16 @@ struct InblockP {
     unsigned xbytes, wbytes;
 };
 
-constexpr int IB_TM = 16, IB_TN = 32, IB_WAVES = 16, IB_MAXS = 9, IB_RING = 5;
+constexpr int IB_TN = 32, IB_WAVES = 16, IB_MAXS = 9;
 
+// PT pixel tiles (of 16) per workgroup: 1 for one or two faces (14x14x256: 104 / 200 workgroups, one round over the CUs), 2 beyond
+// (half the workgroups, each pixel fragment used by both cout tiles as before, each weight fragment by two pixel tiles).  The
+// order in which an output element's products are summed does not depend on PT: the two forms give the same bits.
+template <int PT>
 __global__ __launch_bounds__(IB_WAVES * 64) void conv_inblock_kernel(InblockP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(16))) float part[IB_WAVES][IB_TM][IB_TN];      // 32 KB
+    constexpr int IB_TM = 16 * PT, IB_RING = PT == 1 ? 5 : 4;
+    __shared__ __attribute__((aligned(16))) float part[IB_WAVES][IB_TM][IB_TN];      // 32 / 64 KB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
@@ -39,47 +44,64 @@ __global__ __launch_bounds__(IB_WAVES * 64) void conv_inblock_kernel(InblockP p)
     __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
 
     // the epilogue threads fetch their residual first: it is the longest-latency operand of the tail
-    const int epx = tid & 15, ecq = tid >> 4;                      // tid < 128: pixel epx, couts 4 ecq .. + 3 of the tile
+    const int epx = tid % IB_TM, ecq = tid / IB_TM;                // tid < 8 IB_TM: pixel epx, couts 4 ecq .. + 3 of the tile
     const int em = m0 + epx;
     half4 rv = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-    const bool etail = tid < 128 && em < p.M;
+    const bool etail = tid < 8 * IB_TM && em < p.M;
     if (etail && p.res) rv = *reinterpret_cast<const half4*>(p.res + (size_t)em * p.Cout + n0 + 4 * ecq);
 
-    // this lane's pixel (B operand column fr)
-    const int m = m0 + fr;
-    const bool mv = m < p.M;
+    // this lane's pixels (B operand column fr of pixel tile j)
     const int hw = p.H * p.W;
-    const int n = m / hw, r = m - n * hw, y = r / p.W, x = r - y * p.W;
+    bool mv[PT]; int pn[PT], py[PT], px[PT];
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        const int m = m0 + 16 * j + fr;
+        mv[j] = m < p.M;
+        pn[j] = m / hw;
+        const int r = m - pn[j] * hw;
+        py[j] = r / p.W; px[j] = r - py[j] * p.W;
+    }
     const unsigned wrow0 = (unsigned)((n0 + fr) * p.K + 8 * fq) * 2u, wrow1 = wrow0 + (unsigned)(16 * p.K) * 2u;
     const int ns = (p.nks - wave + IB_WAVES - 1) / IB_WAVES;      // K steps of this wave: wave, wave + 16, ...
 
-    int4v a0[IB_RING], a1[IB_RING], bx[IB_RING];
+    int4v a0[IB_RING], a1[IB_RING], bx[IB_RING][PT];
     auto load = [&](int i, int slot) {
         const int ks = wave + IB_WAVES * i;
         const int tap = ks / p.cpt, cg = ks - tap * p.cpt;
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        const int yy = y + dy, xx = x + dx;
-        const bool ok = mv && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-        const unsigned xo = ok ? (unsigned)(((n * p.H + yy) * p.W + xx) * p.Cin + cg * 32 + 8 * fq) * 2u : 0x80000000u;
         a0[slot] = __builtin_amdgcn_raw_buffer_load_b128(wrs, wrow0 + (unsigned)ks * 64u, 0, 0);
         a1[slot] = __builtin_amdgcn_raw_buffer_load_b128(wrs, wrow1 + (unsigned)ks * 64u, 0, 0);
-        bx[slot] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xo, 0, 0);
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const int yy = py[j] + dy, xx = px[j] + dx;
+            const bool ok = mv[j] && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            const unsigned xo = ok ? (unsigned)(((pn[j] * p.H + yy) * p.W + xx) * p.Cin + cg * 32 + 8 * fq) * 2u : 0x80000000u;
+            bx[slot][j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xo, 0, 0);
+        }
     };
 #pragma unroll
     for (int i = 0; i < IB_RING; ++i)
         if (i < ns) load(i, i);
-    float4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float4v acc[PT][2];
+#pragma unroll
+    for (int j = 0; j < PT; ++j) acc[j][0] = acc[j][1] = float4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < IB_MAXS; ++i) {
         if (i < ns) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a0[i % IB_RING]), __builtin_bit_cast(half8, bx[i % IB_RING]), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a1[i % IB_RING]), __builtin_bit_cast(half8, bx[i % IB_RING]), acc1, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a0[i % IB_RING]), __builtin_bit_cast(half8, bx[i % IB_RING][j]), acc[j][0], 0, 0, 0);
+                acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a1[i % IB_RING]), __builtin_bit_cast(half8, bx[i % IB_RING][j]), acc[j][1], 0, 0, 0);
+            }
             if (i + IB_RING < ns) load(i + IB_RING, i % IB_RING);
         }
     }
-    // lane: pixel fr, couts 4 fq .. + 3 of cout tile 0 (acc0) and 1 (acc1)
-    *reinterpret_cast<float4v*>(&part[wave][fr][4 * fq]) = acc0;
-    *reinterpret_cast<float4v*>(&part[wave][fr][16 + 4 * fq]) = acc1;
+    // lane: pixel fr of tile j, couts 4 fq .. + 3 of cout tile 0 / 1
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        *reinterpret_cast<float4v*>(&part[wave][16 * j + fr][4 * fq]) = acc[j][0];
+        *reinterpret_cast<float4v*>(&part[wave][16 * j + fr][16 + 4 * fq]) = acc[j][1];
+    }
     __syncthreads();
     if (!etail) return;
     float4v v = {0.f, 0.f, 0.f, 0.f};
@@ -118,7 +140,7 @@ extern "C" int fr_conv_inblock_f16(const fr_conv_args* a, fr_stream_t stream) {
                "fr_conv_inblock_f16: Cin %% 32 == 0, Cin <= 512, Cout %% 32 == 0 (got %d, %d)", a->Cin, a->Cout);
     FR_REQUIRE(a->bias_mode == 0 || (a->bias_mode == 1 && a->bias && a->H >= 2 && a->W >= 2), "fr_conv_inblock_f16: bad bias mode");
     const int64_t M = (int64_t)a->B * a->H * a->W;
-    FR_REQUIRE(M * a->Cin * 2 < (1ll << 31) && (int64_t)a->Cout * 9 * a->Cin * 2 < (1ll << 31) && M / IB_TM < 65536,
+    FR_REQUIRE(M * a->Cin * 2 < (1ll << 31) && (int64_t)a->Cout * 9 * a->Cin * 2 < (1ll << 31) && M / 16 < 65536,
                "fr_conv_inblock_f16: tensor too large for this small-batch kernel (B %d)", a->B);
     InblockP p;
     p.x = (const half_t*)a->x; p.w = (const half_t*)a->w; p.y = (half_t*)a->y;
@@ -127,8 +149,15 @@ extern "C" int fr_conv_inblock_f16(const fr_conv_args* a, fr_stream_t stream) {
     p.M = (int)M; p.K = 9 * a->Cin; p.nks = p.K / 32; p.cpt = a->Cin / 32;
     p.xbytes = (unsigned)(M * a->Cin * 2); p.wbytes = (unsigned)((int64_t)a->Cout * p.K * 2);
     static_assert(IB_MAXS * IB_WAVES >= 9 * 512 / 32, "every K step of the largest conv has a wave and a slot");
-    dim3 grid((unsigned)((M + IB_TM - 1) / IB_TM), (unsigned)(a->Cout / IB_TN));
-    conv_inblock_kernel<<<grid, IB_WAVES * 64, 0, fr_stream(stream)>>>(p);
+    // one pixel tile per workgroup while that is at most one round over the CUs' worth of workgroups, two beyond
+    const int64_t wg1 = ((M + 15) / 16) * (a->Cout / IB_TN);
+    if (wg1 <= 256) {
+        dim3 grid((unsigned)((M + 15) / 16), (unsigned)(a->Cout / IB_TN));
+        conv_inblock_kernel<1><<<grid, IB_WAVES * 64, 0, fr_stream(stream)>>>(p);
+    } else {
+        dim3 grid((unsigned)((M + 31) / 32), (unsigned)(a->Cout / IB_TN));
+        conv_inblock_kernel<2><<<grid, IB_WAVES * 64, 0, fr_stream(stream)>>>(p);
+    }
     FR_CHECK_LAUNCH("conv_inblock_kernel");
     return FR_OK;
 }

@@ -30,7 +30,7 @@ FC_SPLITK = 28
 SMALL_BATCH = 48      # measured crossover: 32 faces 2.7 vs 3.3 ms, 64 faces 4.6 vs 3.7 ms
 # up to this many faces the 3x3 / stride-1 convs with >= 128 input channels run split along K INSIDE a workgroup, one launch
 # per conv (fr_conv_inblock_f16) instead of the partials launch + fr_conv_splitk_epilogue (see IResNetHIP._inblock)
-INBLOCK_BATCH = 2
+INBLOCK_BATCH = 4      # measured (tools/bench_inblock.py): 1 face 0.92 vs 1.29 ms, 2: 0.98 / 1.41, 4: 1.33 / 1.64, 6: 2.09 / 1.88
 # up to this many faces (single frames) every K slice is at most 3 K steps long: a slice's steps are dependent HBM
 # round trips (the weights are cold: 130 MB per forward), so a launch takes ~1.2 us per step + ~3 us
 LOW_BATCH = 8
@@ -549,10 +549,10 @@ class IResNetHIP:
         return min(8, nk // 9)
 
     def _inblock(self, c, B):
-        """One or two faces (single frames): a 3x3 / stride-1 conv with >= 128 input channels is ONE launch that splits K
+        """Up to four faces (single frames): a 3x3 / stride-1 conv with >= 128 input channels is ONE launch that splits K
         among the sixteen waves of a workgroup (csrc/conv_inblock.hip) - the split-K form is two launches at their
         latency floor, 89 times per forward.  A mode of its own: inside it a face's embedding does not depend on its
-        batch mate, against the other modes it differs by f32 summation order."""
+        batch mates, against the other modes it differs by f32 summation order."""
         return (B <= self.inblock_batch and c.k == 3 and c.stride == 1 and c.pad == 1 and c.cin % 32 == 0
                 and 128 <= c.cin <= 512 and c.cout % 32 == 0 and isinstance(c, _Conv))
 

@@ -89,10 +89,34 @@ def test_conv_layer_vs_torch(lib, case):
     (1, 28, 28, 128, 256, 1, True, False),       # Cout != Cin
     (3, 5, 9, 160, 96, 1, True, True),           # odd image, 45 K steps, three cout tiles, a tile across two images
     (1, 2, 2, 128, 32, 1, False, False),         # every pixel a corner, one cout tile
+    (4, 14, 14, 256, 256, 1, True, True),        # > 256 workgroups of one pixel tile: the two-tile form (25 x 8 workgroups)
+    (5, 7, 7, 512, 512, 0, False, True),         # two-tile form, 245 pixels = 7 double tiles + 21 pixels, 9 K steps per wave
+    (3, 28, 28, 128, 128, 1, True, False),       # two-tile form at 28 x 28
 ])
 def test_inblock_conv_vs_torch(lib, case):
     B, H, W, Cin, Cout, bias_mode, slope, residual = case
     _conv_case(lib, B, H, W, Cin, Cout, 3, 1, 1, bias_mode, slope, residual, seed=hash(case) & 0xffff, entry="fr_conv_inblock_f16")
+
+
+def test_inblock_conv_tile_forms_give_the_same_bits(lib):
+    """One pixel tile per workgroup (few faces) or two (more): an output element's products are summed in the same order, so
+    a face computed alone (one-tile form) equals the same face inside a batch that takes the two-tile form."""
+    from facerecognition_infrenceengine_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    B, H, C = 4, 14, 256
+    x = torch.randn((B, H, H, C), generator=g).to(torch.float16).cuda()
+    w = (torch.randn((C, 9 * C), generator=g) * 0.02).to(torch.float16).cuda()
+    b = torch.randn(C, generator=g).cuda()
+    def run(xx):
+        n = xx.shape[0]
+        y = torch.empty((n, H, H, C), dtype=torch.float16, device="cuda")
+        a = _lib.ConvArgs(_lib.ptr(xx), _lib.ptr(w), _lib.ptr(y), _lib.ptr(b), None, None, None, n, H, H, C, C, 3, 3, 1, 1, H, H, 0, 1)
+        lib.fr_conv_inblock_f16(ctypes.byref(a), _lib.stream_ptr())
+        return y
+    y4 = run(x)                              # 49 x 8 = 392 workgroups of one tile > 256: two-tile form
+    y1 = run(x[2:3].contiguous())            # 13 x 8: one-tile form
+    torch.cuda.synchronize()
+    assert torch.equal(y4[2:3], y1)
 
 
 def test_inblock_conv_refuses_what_it_cannot_compute(lib):
@@ -114,7 +138,7 @@ def test_inblock_conv_refuses_what_it_cannot_compute(lib):
 
 
 def test_inblock_mode_on_r100_vs_split_k_mode(r100):
-    """One- and two-face forwards take the in-block split-K convs (IResNetHIP.inblock_batch); the same faces through the
+    """Forwards of up to four faces take the in-block split-K convs (IResNetHIP.inblock_batch); the same faces through the
     split-K + epilogue mode (inblock_batch = 0) differ by f32 summation order only, and a face's embedding does not depend
     on its batch mate inside the mode."""
     g = torch.Generator().manual_seed(5)
@@ -277,13 +301,16 @@ def test_r100_batch_independence(r100):
     g = torch.Generator().manual_seed(5)
     x = torch.rand((5, 3, 112, 112), generator=g) * 2 - 1
     xa = nchw_to_nhwc8(x)
-    e_all, n_all = r100.forward(xa)
-    e_three, _ = r100.forward(xa[2:5].contiguous())      # the same batch-size mode (3 .. 8 faces): bit for bit
-    assert torch.equal(e_all[2:5], e_three)
-    e_two, _ = r100.forward(xa[3:5].contiguous())        # the one- / two-face mode (in-block split-K convs): bit for bit inside it,
-    e_one, n_one = r100.forward(xa[3:4].contiguous())    # f32 summation order against the other modes
-    assert torch.equal(e_two[:1], e_one)
-    assert float(1 - (n_all[3:4] * n_one).sum()) < 1e-5
+    x7 = nchw_to_nhwc8(torch.rand((7, 3, 112, 112), generator=g) * 2 - 1)
+    e_all, n_all = r100.forward(x7)
+    e_five, _ = r100.forward(x7[2:7].contiguous())       # the same batch-size mode (5 .. 8 faces): bit for bit
+    assert torch.equal(e_all[2:7], e_five)
+    e_four, _ = r100.forward(xa[1:5].contiguous())       # the mode of up to four faces (in-block split-K convs; its two tile
+    e_two, _ = r100.forward(xa[3:5].contiguous())        # forms give the same bits): bit for bit inside it, f32 summation
+    e_one, n_one = r100.forward(xa[3:4].contiguous())    # order against the other modes
+    assert torch.equal(e_four[2:3], e_one) and torch.equal(e_two[:1], e_one)
+    e_in5, n_in5 = r100.forward(xa)
+    assert float(1 - (n_in5[3:4] * n_one).sum()) < 1e-5
 
 
 def test_prepared_sequence_equals_launch_by_launch(r100, monkeypatch):
