@@ -119,7 +119,10 @@ def _dense_as_conv(w, k, c):
 
 
 class MTCNNHIP:
-    SINGLE_FRAME_LEVEL_STREAMS = 11     # level streams of a single-frame call while it is captured into a HIP graph
+    # level streams of a single-frame call while it is captured into a HIP graph.  Round 3, final kernels (tools/bench_latency_streams.py,
+    # get() + match under replay, 24 / 4 hardware queues): 0 streams 1.81 - 1.84 / 1.80 - 1.84 ms, 2: 1.67 - 1.69 / 1.66 - 1.74, 4: 1.59 - 1.65 /
+    # 1.58 - 1.64, 11 (one per level, the earlier default): 1.70 - 1.74 / 1.57 - 1.66
+    SINGLE_FRAME_LEVEL_STREAMS = 4
     def __init__(self, pstate, rstate, ostate, device="cuda:0", minsize=20, factor=0.709,
                  thresholds=(0.6, 0.7, 0.7), cap_scale=2048, keep_scale=256, cap_p=512, cap_r=64, cap_o=16,
                  fused_pnet=True):

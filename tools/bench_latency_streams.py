@@ -8,6 +8,6 @@ from facerecognition_infrenceengine_amd.mtcnn import MTCNNHIP
 warnings.simplefilter("ignore")
 dev = torch.device("cuda:0")
 app = FaceAnalysis(name="synthetic", arch="r100", cap_o=4).prepare(ctx_id=0)
-for n in (0, 11, 0, 11, 4):
+for n in (0, 11, 2, 4, 0, 11, 2, 4):
     MTCNNHIP.SINGLE_FRAME_LEVEL_STREAMS = n          # c1_latency clones the engine: the clone's detector reads the class default
     print("single_frame_level_streams", n, bench.c1_latency(app, dev, n=40), flush=True)
