@@ -5,6 +5,7 @@ a launch plan only: every stage works on fixed-capacity per-frame slot lists wit
 counts, so a whole batch of frames runs without a host synchronisation.  Conventions (resize,
 ordering, thresholds, capacities) are those written down in ``oracle/detect.py``.
 """
+import contextlib
 import math
 import threading
 
@@ -193,11 +194,29 @@ class MTCNNHIP:
         self._tls.s = v
 
     # ---- thin launch helpers (all on the current stream)
+    def _new(self, shape, dtype):
+        """A work tensor.  Inside an eager single-frame call (``detect_batch`` sets ``_tls.cache``) the k-th allocation of a
+        call returns the tensor the k-th allocation of the previous call with the same frame shape, stream and thread
+        made: ~90 ``torch.empty`` per call were 0.15 ms of an interpreter-bound 0.73 ms."""
+        c = getattr(self._tls, "cache", None)
+        if c is None:
+            return torch.empty(shape, dtype=dtype, device=self.device)
+        lst, i = c
+        c[1] = i + 1
+        if i < len(lst) and lst[i].shape == tuple(shape) and lst[i].dtype == dtype:
+            return lst[i]
+        t = torch.empty(shape, dtype=dtype, device=self.device)
+        if i < len(lst):
+            lst[i] = t
+        else:
+            lst.append(t)
+        return t
+
     def _f32(self, *shape):
-        return torch.empty(shape, dtype=torch.float32, device=self.device)
+        return self._new(shape, torch.float32)
 
     def _i32(self, *shape):
-        return torch.empty(shape, dtype=torch.int32, device=self.device)
+        return self._new(shape, torch.int32)
 
     def _dconv(self, x, c, B, H, W, frames=None, counts=None, cap=0, y_split=None):
         ho, wo = c.out_hw(H, W)
@@ -238,11 +257,11 @@ class MTCNNHIP:
         # the pyramid level is resized inside P-Net conv1's tile load (no f32 level image in HBM)
         h, w = self.p1.out_hw(hs, ws)
         if self.fused_pnet and N * h * w * 64 < 2 ** 31:          # the split map is addressed with 32-bit buffer offsets
-            xs = torch.empty((N, h, w, 64), dtype=torch.uint8, device=self.device)     # split-f16 copy of conv1's map
+            xs = self._new((N, h, w, 64), torch.uint8)     # split-f16 copy of conv1's map
             x, h, w = self._dconv(None, self.p1, N, hs, ws, frames=frames, y_split=xs)
             t0 = self.thresholds[0]
             head = self._f32(N, h - 4, w - 4, 6)
-            ws = torch.empty(self.lib.fr_pnet23_workspace_bytes(N, h, w) // 4, dtype=torch.float32, device=self.device)
+            ws = self._new((self.lib.fr_pnet23_workspace_bytes(N, h, w) // 4,), torch.float32)
             self.lib.fr_pnet23_split_f16(_lib.ptr(x), _lib.ptr(xs), N, h, w, *[_lib.ptr(t) for t in self._p23], _lib.ptr(head),
                                          1 if (self.p23_all_heads or trace is not None) else 0, math.log(t0 / (1.0 - t0)) - self.refine_margin, _lib.ptr(self.refined_cells),
                                          _lib.ptr(ws), ws.numel() * 4, self._s)
@@ -316,6 +335,7 @@ class MTCNNHIP:
         lib, t0, t1, t2 = self.lib, *self.thresholds
         with torch.cuda.device(self.device):
             self._s = _lib.stream_ptr()
+            self._tls.cache = None              # (a call that raised may have left it set)
             self._mark("start")
             scales = pyramid_scales(H, W, self.minsize, self.factor)
             nlev = len(scales)
@@ -345,12 +365,23 @@ class MTCNNHIP:
                 while len(sides) < nside:
                     sides.append(torch.cuda.Stream(device=self.device))
             sides = sides[:nside]
-            for side in sides:
-                side.wait_stream(main)
+            # An EAGER single-frame call is bound by the interpreter (host issue 0.73 ms against 0.85 ms until the GPU is done,
+            # tools/host_time_c1.py): side streams would only add their fork / join events and a stream switch per level
+            solo = trace is not None or self.one_stream or (N < 8 and level_streams is None and not torch.cuda.is_current_stream_capturing())
+            if solo and trace is None and N < 8 and not torch.cuda.is_current_stream_capturing():
+                caches = self._tls.__dict__.setdefault("caches", {})
+                key = (N, H, W, main.cuda_stream)
+                if key not in caches and len(caches) >= 4:
+                    caches.pop(next(iter(caches)))                  # oldest frame shape of this thread
+                self._tls.cache = [caches.setdefault(key, []), 0]
+            if not solo:
+                for side in sides:
+                    side.wait_stream(main)
             for li, s in enumerate(scales):
                 side = sides[(li - 1) % len(sides)] if li else sides[0]
-                with torch.cuda.stream(main if li == 0 or trace is not None or self.one_stream else side):
-                    self._s = _lib.stream_ptr()
+                with (contextlib.nullcontext() if solo else torch.cuda.stream(main if li == 0 else side)):
+                    if not solo:
+                        self._s = _lib.stream_ptr()
                     head, hc, wc = self.pnet_level(frames, s, trace)
                     nblk = -(-hc * wc // 256)
                     bc = self._i32(N * nblk)
@@ -366,9 +397,10 @@ class MTCNNHIP:
                     if trace is not None:
                         trace.setdefault("pnet_head", []).append(head)
                         trace.setdefault("pnet_prob", []).append(prob)
-            for side in sides:
-                main.wait_stream(side)
-            self._s = _lib.stream_ptr()
+            if not solo:
+                for side in sides:
+                    main.wait_stream(side)
+                self._s = _lib.stream_ptr()
             self._mark("pnet")
             if N < 8 or self.merged_level_nms:
                 self._nms(lb, ls, lr, 4, lc, nlev * N, 1, cs, 0, 0.5, 0, ksz, out=(kb, ks, ka, kc))
@@ -412,6 +444,7 @@ class MTCNNHIP:
             lib.fr_stage_select(_lib.ptr(b2), _lib.ptr(head3), 16, _lib.ptr(c2), N, self.cap_r, t2, _lib.ptr(tb),
                                 _lib.ptr(ts), _lib.ptr(ta), 14, _lib.ptr(tc), _lib.ptr(prob3), self._s)
             lib.fr_box_refine(_lib.ptr(tb), _lib.ptr(ta), 14, _lib.ptr(tc), N, self.cap_r, 2, self._s)
+            self._tls.cache = None                      # what is returned to the caller is never a cached work tensor
             b3, s3, a3, c3 = self._nms(tb, ts, ta, 14, tc, N, 1, self.cap_r, 0, 0.7, 1, self.cap_o)
             self._mark("stage3")
             if trace is not None:
