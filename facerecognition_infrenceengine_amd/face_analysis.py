@@ -163,13 +163,19 @@ class FaceAnalysis:
         boxes, scores, kps, counts = self.det.detect_batch(frames)
         cap = boxes.shape[1]
         cnt = counts.cpu()                                            # the one sync of the pipeline
-        mask = torch.arange(cap)[None, :] < cnt[:, None]
-        sel = mask.reshape(-1).nonzero().squeeze(1).to(self.device)   # frame-major valid slots
-        F = sel.numel()
-        frame_idx = (sel // cap).to(torch.int32)
-        out = {"counts": cnt.tolist(), "frame_idx": frame_idx,
-               "bbox": boxes.reshape(-1, 4)[sel], "kps": kps.reshape(-1, 5, 2)[sel].contiguous(),
-               "det_score": scores.reshape(-1)[sel]}
+        if N == 1:                                                    # a single frame: its valid slots are a prefix - views, no gathers
+            F = int(cnt[0])
+            frame_idx = torch.zeros(F, dtype=torch.int32, device=self.device)
+            out = {"counts": [F], "frame_idx": frame_idx, "bbox": boxes[0, :F], "kps": kps[0, :F].contiguous(),
+                   "det_score": scores[0, :F]}
+        else:
+            mask = torch.arange(cap)[None, :] < cnt[:, None]
+            sel = mask.reshape(-1).nonzero().squeeze(1).to(self.device)   # frame-major valid slots
+            F = sel.numel()
+            frame_idx = (sel // cap).to(torch.int32)
+            out = {"counts": cnt.tolist(), "frame_idx": frame_idx,
+                   "bbox": boxes.reshape(-1, 4)[sel], "kps": kps.reshape(-1, 5, 2)[sel].contiguous(),
+                   "det_score": scores.reshape(-1)[sel]}
         emb = torch.empty((F, 512), dtype=torch.float32, device=self.device)
         normed = torch.empty_like(emb)
         if F:
@@ -276,7 +282,12 @@ class FaceAnalysis:
         with self._lock:
             dev = torch.from_numpy(arr).to(self.device)
             r = self.detect_embed_device(dev)
-            host = {k: r[k].cpu().numpy() for k in ("bbox", "kps", "det_score", "embedding", "normed_embedding")}
+            # ONE device-to-host copy (and sync) for the five result tensors instead of five
+            F = r["bbox"].shape[0]
+            pack = torch.cat([r["bbox"].reshape(F, 4), r["kps"].reshape(F, 10), r["det_score"].reshape(F, 1),
+                              r["embedding"], r["normed_embedding"]], dim=1).cpu().numpy()
+            host = {"bbox": pack[:, 0:4], "kps": pack[:, 4:14].reshape(F, 5, 2), "det_score": pack[:, 14],
+                    "embedding": pack[:, 15:527], "normed_embedding": pack[:, 527:1039]}
         res, i = [], 0
         for n in r["counts"]:
             faces = []
