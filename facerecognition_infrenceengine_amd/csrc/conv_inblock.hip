@@ -49,6 +49,21 @@ __global__ __launch_bounds__(IB_WAVES * 64) void conv_inblock_kernel(InblockP p)
     half4 rv = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
     const bool etail = tid < 8 * IB_TM && em < p.M;
     if (etail && p.res) rv = *reinterpret_cast<const half4*>(p.res + (size_t)em * p.Cout + n0 + 4 * ecq);
+    // ... and their bias and slope rows: behind the barrier these were a second exposed round trip per launch
+    float4v ebias = {0.f, 0.f, 0.f, 0.f}, eslope = {1.f, 1.f, 1.f, 1.f};
+    if (etail) {
+        const int co_ = n0 + 4 * ecq;
+        if (p.bias) {
+            int bsel = 0;
+            if (p.bias_mode == 1) {
+                const int hw_ = p.H * p.W, er = em % hw_, ho = er / p.W, wo = er - ho * p.W;
+                const int rc = ho == 0 ? 0 : (ho == p.H - 1 ? 2 : 1), cc = wo == 0 ? 0 : (wo == p.W - 1 ? 2 : 1);
+                bsel = (rc * 3 + cc) * p.Cout;
+            }
+            ebias = *reinterpret_cast<const float4v*>(p.bias + bsel + co_);
+        }
+        if (p.slope) eslope = *reinterpret_cast<const float4v*>(p.slope + co_);
+    }
 
     // this lane's pixels (B operand column fr of pixel tile j)
     const int hw = p.H * p.W;
@@ -108,19 +123,10 @@ __global__ __launch_bounds__(IB_WAVES * 64) void conv_inblock_kernel(InblockP p)
 #pragma unroll
     for (int w = 0; w < IB_WAVES; ++w) v += *reinterpret_cast<const float4v*>(&part[w][epx][4 * ecq]);
     const int co = n0 + 4 * ecq;
-    if (p.bias) {
-        int bsel = 0;
-        if (p.bias_mode == 1) {
-            const int er = em % hw, ho = er / p.W, wo = er - ho * p.W;
-            const int rc = ho == 0 ? 0 : (ho == p.H - 1 ? 2 : 1), cc = wo == 0 ? 0 : (wo == p.W - 1 ? 2 : 1);
-            bsel = (rc * 3 + cc) * p.Cout;
-        }
-        v += *reinterpret_cast<const float4v*>(p.bias + bsel + co);
-    }
+    if (p.bias) v += ebias;
     if (p.slope) {
-        const float4v sv = *reinterpret_cast<const float4v*>(p.slope + co);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.f ? v[c] : v[c] * sv[c];
+        for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.f ? v[c] : v[c] * eslope[c];
     }
     if (p.res) {
 #pragma unroll
