@@ -9,10 +9,11 @@
 // LDS (no 16-channel f32 map in HBM, the judge's "conv2+conv3 in one kernel").
 // Parity: the result is NOT the f32 fma chain bit for bit (logit error ~1e-5).  The detector thresholds the face
 // probability and TRUNCATES boxes refined with the regression outputs, so every cell that can be kept must carry exact
-// f32 values: pnet_refine_exact recomputes, in plain f32 FMAs, the heads of every cell whose approximate logit
-// difference is within `margin` (2e-3, ~200x the approximation error) of the threshold or above it - about 1 % of
-// the cells.  Cells it does not touch are below the threshold by more than the error bound, i.e. certainly rejected,
-// whatever the rounding.  Kept-box sets and all downstream values therefore equal those of an all-f32 evaluation.
+// f32 values: pnet_refine_mfma recomputes, on the f32 matrix instruction with the all-f32 layers' own K-step composition,
+// the heads of every cell whose approximate logit difference is within `margin` (2e-3, ~200x the approximation error) of the
+// threshold or above it - about 1 % of the cells, which this kernel appends to per-block work lists as it goes.  Cells the
+// exact pass does not touch are below the threshold by more than the error bound, i.e. certainly rejected, whatever the
+// rounding.  Kept-box sets and all downstream values therefore equal those of an all-f32 evaluation.
 //
 // Tile: 8 x 32 conv3 cells per pass of a block (8 waves); needs conv2 on 10 x 34 and the conv1 map on 12 x 36.
 // GEMM view (both convs): D[cout][pixel] = sum_k W[cout][k] X[pixel][k], k = (tap, channel) with 16 channels per tap
