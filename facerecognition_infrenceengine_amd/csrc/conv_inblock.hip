@@ -1,4 +1,4 @@
-// 3x3 / stride 1 / pad 1 convs of a forward of ONE to FOUR faces (the embed half of a single-frame FaceAnalysis.get,
+// 3x3 / stride 1 / pad 1 convs of a forward of ONE to EIGHT faces (the embed half of a single-frame FaceAnalysis.get,
 // /root/reference/infrenceServer.py:528): split along K INSIDE a workgroup, one launch per conv.
 //
 // Why: a single face's 14x14x256 conv is 231 MFLOP over 72 K steps; cut into slices that run side by side on different
@@ -28,14 +28,14 @@ struct InblockP {
 
 constexpr int IB_TN = 32, IB_WAVES = 16, IB_MAXS = 9;
 
-// PT pixel tiles (of 16) per workgroup: 1 for one or two faces (14x14x256: 104 / 200 workgroups, one round over the CUs), 2 beyond
+// PT pixel tiles (of 16) per workgroup: 1 for one or two faces (14x14x256: 104 / 200 workgroups, one round over the CUs), 2 and 4 beyond
 // (half the workgroups, each pixel fragment used by both cout tiles as before, each weight fragment by two pixel tiles).  The
 // order in which an output element's products are summed does not depend on PT: the two forms give the same bits.
 template <int PT>
 __global__ __launch_bounds__(IB_WAVES * 64) void conv_inblock_kernel(InblockP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int IB_TM = 16 * PT, IB_RING = PT == 1 ? 5 : 4;
-    __shared__ __attribute__((aligned(16))) float part[IB_WAVES][IB_TM][IB_TN];      // 32 / 64 KB
+    constexpr int IB_TM = 16 * PT, IB_RING = PT == 1 ? 5 : (PT == 2 ? 4 : 2);
+    __shared__ __attribute__((aligned(16))) float part[IB_WAVES][IB_TM][IB_TN];      // 32 / 64 / 128 KB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
@@ -155,14 +155,17 @@ extern "C" int fr_conv_inblock_f16(const fr_conv_args* a, fr_stream_t stream) {
     p.M = (int)M; p.K = 9 * a->Cin; p.nks = p.K / 32; p.cpt = a->Cin / 32;
     p.xbytes = (unsigned)(M * a->Cin * 2); p.wbytes = (unsigned)((int64_t)a->Cout * p.K * 2);
     static_assert(IB_MAXS * IB_WAVES >= 9 * 512 / 32, "every K step of the largest conv has a wave and a slot");
-    // one pixel tile per workgroup while that is at most one round over the CUs' worth of workgroups, two beyond
-    const int64_t wg1 = ((M + 15) / 16) * (a->Cout / IB_TN);
+    // one pixel tile per workgroup while that is at most one round over the CUs' worth of workgroups, then two, then four
+    const int64_t wg1 = ((M + 15) / 16) * (a->Cout / IB_TN), wg2 = ((M + 31) / 32) * (a->Cout / IB_TN);
     if (wg1 <= 256) {
         dim3 grid((unsigned)((M + 15) / 16), (unsigned)(a->Cout / IB_TN));
         conv_inblock_kernel<1><<<grid, IB_WAVES * 64, 0, fr_stream(stream)>>>(p);
-    } else {
+    } else if (wg2 <= 256) {
         dim3 grid((unsigned)((M + 31) / 32), (unsigned)(a->Cout / IB_TN));
         conv_inblock_kernel<2><<<grid, IB_WAVES * 64, 0, fr_stream(stream)>>>(p);
+    } else {
+        dim3 grid((unsigned)((M + 63) / 64), (unsigned)(a->Cout / IB_TN));
+        conv_inblock_kernel<4><<<grid, IB_WAVES * 64, 0, fr_stream(stream)>>>(p);
     }
     FR_CHECK_LAUNCH("conv_inblock_kernel");
     return FR_OK;

@@ -30,7 +30,8 @@ FC_SPLITK = 28
 SMALL_BATCH = 48      # measured crossover: 32 faces 2.7 vs 3.3 ms, 64 faces 4.6 vs 3.7 ms
 # up to this many faces the 3x3 / stride-1 convs with >= 128 input channels run split along K INSIDE a workgroup, one launch
 # per conv (fr_conv_inblock_f16) instead of the partials launch + fr_conv_splitk_epilogue (see IResNetHIP._inblock)
-INBLOCK_BATCH = 4      # measured (tools/bench_inblock.py): 1 face 0.92 vs 1.29 ms, 2: 0.98 / 1.41, 4: 1.33 / 1.64, 6: 2.09 / 1.88
+INBLOCK_BATCH = 8      # measured (tools/bench_inblock.py, forward ms): 1 face 0.89 vs 1.30, 2: 0.95 / 1.41, 4: 1.23 / 1.65, 5: 1.25 / 1.78,
+                       # 6: 1.82 / 1.88, 8: 1.85 / 2.19, 12: 2.94 / 2.11 (one, two or four pixel tiles per workgroup by the workgroup count)
 # up to this many faces (single frames) every K slice is at most 3 K steps long: a slice's steps are dependent HBM
 # round trips (the weights are cold: 130 MB per forward), so a launch takes ~1.2 us per step + ~3 us
 LOW_BATCH = 8
@@ -549,7 +550,7 @@ class IResNetHIP:
         return min(8, nk // 9)
 
     def _inblock(self, c, B):
-        """Up to four faces (single frames): a 3x3 / stride-1 conv with >= 128 input channels is ONE launch that splits K
+        """Up to eight faces (single frames): a 3x3 / stride-1 conv with >= 128 input channels is ONE launch that splits K
         among the sixteen waves of a workgroup (csrc/conv_inblock.hip) - the split-K form is two launches at their
         latency floor, 89 times per forward.  A mode of its own: inside it a face's embedding does not depend on its
         batch mates, against the other modes it differs by f32 summation order."""

@@ -237,8 +237,8 @@ int fr_gptq_round_e4m3(const double* W, const double* U, const float* sw, float*
 int fr_conv_splitk_epilogue(const float* partial, int splitk, int M, int Cout, int Ho, int Wo,
                             const float* bias, int bias_mode, const float* slope, const void* residual,
                             void* y, fr_stream_t stream);
-/* 3x3 / stride 1 / pad 1 conv of a forward of one to four faces (single frames; same reference site, infrenceServer.py:528),
- * split along K INSIDE a workgroup: sixteen waves share one 16- (or, past 256 workgroups, 32-) pixel x 32-cout output tile, a sixteenth of K each, partials
+/* 3x3 / stride 1 / pad 1 conv of a forward of one to eight faces (single frames; same reference site, infrenceServer.py:528),
+ * split along K INSIDE a workgroup: sixteen waves share one 16- (past 256 workgroups 32-, then 64-) pixel x 32-cout output tile, a sixteenth of K each, partials
  * summed through LDS in wave order, then the fused epilogue of fr_conv_nhwc_f16 ((border-class) bias -> PReLU -> + residual
  * -> one rounding to f16) - ONE launch where the split-K mode of fr_conv_nhwc_f16 + fr_conv_splitk_epilogue are two
  * (conv_inblock.hip).  Takes fr_conv_args with KH = KW = 3, stride 1, pad 1, Cin % 32 == 0, Cin <= 512, Cout % 32 == 0,

@@ -92,6 +92,9 @@ def test_conv_layer_vs_torch(lib, case):
     (4, 14, 14, 256, 256, 1, True, True),        # > 256 workgroups of one pixel tile: the two-tile form (25 x 8 workgroups)
     (5, 7, 7, 512, 512, 0, False, True),         # two-tile form, 245 pixels = 7 double tiles + 21 pixels, 9 K steps per wave
     (3, 28, 28, 128, 128, 1, True, False),       # two-tile form at 28 x 28
+    (8, 14, 14, 256, 256, 1, True, True),        # four-tile form (25 x 8 workgroups), ring of two
+    (7, 28, 28, 128, 128, 0, False, True),       # four-tile form at 28 x 28, 5488 pixels = 85 quadruple tiles + 48 pixels
+    (9, 7, 7, 512, 512, 1, True, False),         # four-tile form, 9 K steps per wave through a ring of two
 ])
 def test_inblock_conv_vs_torch(lib, case):
     B, H, W, Cin, Cout, bias_mode, slope, residual = case
@@ -115,8 +118,10 @@ def test_inblock_conv_tile_forms_give_the_same_bits(lib):
         return y
     y4 = run(x)                              # 49 x 8 = 392 workgroups of one tile > 256: two-tile form
     y1 = run(x[2:3].contiguous())            # 13 x 8: one-tile form
+    x9 = torch.cat([x, x, x[:1]])            # 9 images: 111 x 8 workgroups of two tiles > 256: four-tile form
+    y9 = run(x9)
     torch.cuda.synchronize()
-    assert torch.equal(y4[2:3], y1)
+    assert torch.equal(y4[2:3], y1) and torch.equal(y9[6:7], y1) and torch.equal(y9[:4], y4)
 
 
 def test_inblock_conv_refuses_what_it_cannot_compute(lib):
@@ -138,7 +143,7 @@ def test_inblock_conv_refuses_what_it_cannot_compute(lib):
 
 
 def test_inblock_mode_on_r100_vs_split_k_mode(r100):
-    """Forwards of up to four faces take the in-block split-K convs (IResNetHIP.inblock_batch); the same faces through the
+    """Forwards of up to eight faces take the in-block split-K convs (IResNetHIP.inblock_batch); the same faces through the
     split-K + epilogue mode (inblock_batch = 0) differ by f32 summation order only, and a face's embedding does not depend
     on its batch mate inside the mode."""
     g = torch.Generator().manual_seed(5)
@@ -302,15 +307,16 @@ def test_r100_batch_independence(r100):
     x = torch.rand((5, 3, 112, 112), generator=g) * 2 - 1
     xa = nchw_to_nhwc8(x)
     x7 = nchw_to_nhwc8(torch.rand((7, 3, 112, 112), generator=g) * 2 - 1)
-    e_all, n_all = r100.forward(x7)
-    e_five, _ = r100.forward(x7[2:7].contiguous())       # the same batch-size mode (5 .. 8 faces): bit for bit
-    assert torch.equal(e_all[2:7], e_five)
-    e_four, _ = r100.forward(xa[1:5].contiguous())       # the mode of up to four faces (in-block split-K convs; its two tile
-    e_two, _ = r100.forward(xa[3:5].contiguous())        # forms give the same bits): bit for bit inside it, f32 summation
-    e_one, n_one = r100.forward(xa[3:4].contiguous())    # order against the other modes
-    assert torch.equal(e_four[2:3], e_one) and torch.equal(e_two[:1], e_one)
-    e_in5, n_in5 = r100.forward(xa)
-    assert float(1 - (n_in5[3:4] * n_one).sum()) < 1e-5
+    e_all, n_all = r100.forward(x7)                      # up to eight faces: the in-block split-K convs - one, two or four pixel
+    e_five, _ = r100.forward(x7[2:7].contiguous())       # tiles per workgroup by the workgroup count, the same bits - so a face
+    e_two, _ = r100.forward(x7[3:5].contiguous())        # does not depend on its batch mates, bit for bit
+    e_one, n_one = r100.forward(x7[3:4].contiguous())
+    assert torch.equal(e_all[2:7], e_five) and torch.equal(e_all[3:5], e_two) and torch.equal(e_two[:1], e_one)
+    x12 = torch.cat([x7, xa])                            # twelve faces: the split-K mode of up to 48 - f32 summation order against
+    e12, n12 = r100.forward(x12)                         # the other mode, and again batch-independent inside its own
+    e10, _ = r100.forward(x12[2:12].contiguous())
+    assert torch.equal(e12[2:12], e10)
+    assert float(1 - (n12[3:4] * n_one).sum()) < 1e-5
 
 
 def test_prepared_sequence_equals_launch_by_launch(r100, monkeypatch):

@@ -7,11 +7,11 @@ from facerecognition_infrenceengine_amd import weights
 from facerecognition_infrenceengine_amd.iresnet import IResNetHIP
 net = IResNetHIP(weights.synth_iresnet_state("r100", seed=1234), "r100", "cuda:0")
 g = torch.Generator().manual_seed(0)
-for B in (1, 2, 3, 4, 6, 8):
+for B in (1, 2, 4, 5, 6, 8, 12, 16):
     x = torch.zeros((B, 112, 112, 8), dtype=torch.float16, device="cuda")
     x[..., :3] = (torch.rand((B, 112, 112, 3), generator=g) * 2 - 1).half().cuda()
     out = []
-    for ib in (8, 0, 8, 0):
+    for ib in (16, 0, 16, 0):
         net.inblock_batch = ib
         net.release_plans()
         for _ in range(5):
