@@ -323,13 +323,19 @@ def _faces_from_slots(counts, host):
 
 
 class _GraphedPipeline:
-    """frames (pinned) -> H2D -> [captured: detect -> align -> embed, fixed slots] -> D2H (pinned), one shape."""
+    """frames (pinned) -> H2D -> [captured: detect -> align -> embed, fixed slots] -> D2H (pinned), one shape.
+
+    A single frame with more than one face slot (``cap_o`` > 1) is captured in TWO parts: the detector, then - behind one read
+    of the face count - align + embed for 1, 2, 4, 8 ... slots, one graph per size, captured when first needed.  One
+    graph over all ``cap_o`` slots (the only form for several frames, and for one slot) embeds every slot whatever the
+    frame holds: with the default 16 slots a one-face frame paid a 16-face forward (2.1 ms against 0.9)."""
 
     def __init__(self, app, shape):
         self.app, dev = app, app.device
         self.h_in = torch.empty(shape, dtype=torch.uint8).pin_memory()
         self.d_in = torch.empty(shape, dtype=torch.uint8, device=dev)
         self.stream = torch.cuda.Stream(device=dev)
+        self.split = shape[0] == 1 and app.det.cap_o > 1
         with torch.cuda.device(dev):
             self.stream.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(self.stream):
@@ -338,9 +344,39 @@ class _GraphedPipeline:
             self.stream.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.stream):
-                self.out = app.detect_embed_slots(self.d_in)
-        self.h_out = {k: torch.empty(self.out[k].shape, dtype=self.out[k].dtype).pin_memory()
-                      for k in _GRAPH_KEYS + ("counts",)}
+                if self.split:
+                    boxes, scores, kps, counts = app.det.detect_batch(self.d_in)
+                    self.out = {"counts": counts, "bbox": boxes, "kps": kps.contiguous(), "det_score": scores}
+                else:
+                    self.out = app.detect_embed_slots(self.d_in)
+        keys = ("bbox", "kps", "det_score", "counts") if self.split else _GRAPH_KEYS + ("counts",)
+        self.h_out = {k: torch.empty(self.out[k].shape, dtype=self.out[k].dtype).pin_memory() for k in keys}
+        self.embed = {}                                   # slots -> (graph, embedding, normed, pinned host copies)
+        if self.split:
+            self.fidx = torch.zeros(app.det.cap_o, dtype=torch.int32, device=dev)
+
+    def _embed_graph(self, n):
+        g = self.embed.get(n)
+        if g is None:
+            app, dev = self.app, self.app.device
+            _, H, W, _ = self.d_in.shape
+            crops = torch.empty((n, 112, 112, 8), dtype=torch.float16, device=dev)
+            kps = self.out["kps"][0, :n]                  # the frame's first n slots: a contiguous prefix
+
+            def body():
+                # slots at or past the face count are zero-filled by the kernel (count read on the device)
+                app.lib.fr_warp_affine_5pt(_lib.ptr(self.d_in), 1, H, W, _lib.ptr(kps), _lib.ptr(self.fidx), _lib.ptr(self.out["counts"]),
+                                           n, 112, _lib.ptr(crops), None, None, _lib.stream_ptr())
+                return app.rec.forward(crops)
+            with torch.cuda.device(dev), torch.cuda.stream(self.stream):
+                body()
+                self.stream.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=self.stream):
+                    emb, normed = body()
+            g = self.embed[n] = (graph, emb, normed, torch.empty((n, 512), dtype=torch.float32).pin_memory(),
+                                 torch.empty((n, 512), dtype=torch.float32).pin_memory(), crops, kps)
+        return g
 
     def run(self, arr):
         self.h_in.numpy()[...] = arr
@@ -350,7 +386,25 @@ class _GraphedPipeline:
             for k, h in self.h_out.items():
                 h.copy_(self.out[k], non_blocking=True)
         self.stream.synchronize()
-        return self.h_out["counts"].numpy().copy(), {k: self.h_out[k].numpy() for k in _GRAPH_KEYS}
+        counts = self.h_out["counts"].numpy().copy()
+        if not self.split:
+            return counts, {k: self.h_out[k].numpy() for k in _GRAPH_KEYS}
+        host = {k: self.h_out[k].numpy() for k in ("bbox", "kps", "det_score")}
+        F = int(counts[0])
+        cap = self.app.det.cap_o
+        host["embedding"] = host["normed_embedding"] = np.zeros((0, 512), dtype=np.float32)
+        if F:
+            n = 1
+            while n < F:
+                n *= 2
+            graph, emb, normed, h_e, h_n = self._embed_graph(min(n, cap))[:5]
+            with torch.cuda.stream(self.stream):
+                graph.replay()
+                h_e.copy_(emb, non_blocking=True)
+                h_n.copy_(normed, non_blocking=True)
+            self.stream.synchronize()
+            host["embedding"], host["normed_embedding"] = h_e.numpy(), h_n.numpy()
+        return counts, host
 
 
 FaceEngine = FaceAnalysis

@@ -328,6 +328,31 @@ def test_graph_replay_equals_eager(app):
             eng.enable_graphs(False)
 
 
+def test_graph_replay_of_a_single_frame_embeds_only_the_slots_it_needs(app):
+    """A single frame on an engine with several face slots is captured in two parts (detector | align + embed for 1, 2, 4, 8 ...
+    slots, chosen by the face count): a frame with a few faces takes a small embed graph - the same batch-size mode as the
+    eager call - and the Face lists agree bit for bit; frames with other counts reuse or add graphs."""
+    from make_golden import synth_frame
+    eng = app.clone_with(cap_o=16, thresholds=(0.6, 0.7, 0.78))       # a stricter O-Net threshold: 2 - 5 faces per frame, 16 slots
+    frames = [synth_frame(240, 320, s) for s in (4, 5, 6, 7, 8)]
+    eager = [eng.get(f) for f in frames]
+    counts = sorted(len(e) for e in eager)
+    assert 1 <= counts[0] and counts[-1] <= 8 and len(set(counts)) >= 3, counts
+    try:
+        eng.enable_graphs(True)
+        for _ in range(2):
+            for f, want in zip(frames, eager):
+                got = eng.get(f)
+                assert len(got) == len(want)
+                for a, b in zip(want, got):
+                    assert np.array_equal(a.bbox, b.bbox) and np.array_equal(a.kps, b.kps) and a.det_score == b.det_score
+                    assert np.array_equal(a.embedding, b.embedding) and np.array_equal(a.normed_embedding, b.normed_embedding)
+        pipe = eng._graphs[(1, 240, 320, 3)]
+        assert pipe.split and 1 <= len(pipe.embed) <= 4 and max(pipe.embed) <= 8
+    finally:
+        eng.enable_graphs(False)
+
+
 def test_model_pack_on_disk_round_trips_through_load_state(app, tmp_path):
     """The drop-in loads `<root>/models/<name>/arcface_<arch>.{safetensors,pt}` + `mtcnn_{pnet,rnet,onet}.pt`
     (weights.load_state).  A pack written from the synthetic state dicts must give the synthetic engine's results

@@ -8,7 +8,7 @@ with warnings.catch_warnings():
     app = FaceAnalysis(name="x").prepare(ctx_id=0)
 frame = synth_frame(480, 640, 7)
 fc = os.environ.get("FR_FUSED_CROP")
-for cap, eng in (("16", app), ("4", app.clone_with(cap_o=4)), ("1", app.clone_with(cap_o=1))):
+for cap, eng in (("16", app), ("16 strict", app.clone_with(cap_o=16, thresholds=(0.6, 0.7, 0.86))), ("4", app.clone_with(cap_o=4)), ("1", app.clone_with(cap_o=1))):
     if fc is not None:
         eng.det.fused_crop = fc == "1"
     for g in (False, True):
