@@ -39,8 +39,10 @@ LOW_BATCH = 8
 MAX_PLAN_STREAMS = 8
 # from this many faces up the stride-1 blocks of the 14x14 stage run as ONE launch with the image resident in LDS
 # (fr_conv_stage14_f16: one workgroup per image, one image per CU); below, the per-layer path fills the CUs better
-# (measured r100 forward, stage / layer by layer: 128 faces 4.62 / 4.44 ms, 160: 5.16 / 5.74, 192: 5.49 / 6.17, 256: 6.8 / 7.6)
-STAGE14_MIN_BATCH = 144
+# (measured r100 forward ALONE, stage / layer by layer: 128 faces 4.62 / 4.44 ms, 160: 5.16 / 5.74, 192: 5.49 / 6.17, 256: 6.8 / 7.6).
+# Taken from 128 faces all the same: in a pipeline the CUs a 128-workgroup launch leaves free are the detector's - config C3 (8 x 4K
+# frames, 128 faces per step; tools/ab_c3_stage_min.py, same box): 19 640 - 19 820 faces/s with the threshold at 144, 20 430 - 20 550 at 128
+STAGE14_MIN_BATCH = 128
 # fr_conv_walk64_f16: one workgroup per (face, 64-cout group), a face's walk cut into 2 / 4 / 8 pieces while that fills <= 256
 # CUs.  Measured (tools/bench_walk64_crossover.py, r100 forward): it beats the per-tile kernel at 64 / 96 / 128 faces (cut walks) and
 # from 160 up; between 129 and 159 faces an uncut walk leaves 40 % of the CUs idle and loses by 1 %.  Not in the small-batch

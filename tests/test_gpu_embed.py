@@ -560,7 +560,7 @@ def test_stage28_path_on_r100_equals_layer_path(r100):
 
 
 def test_stage14_path_on_r100_vs_golden_and_layer_path(r100, golden):
-    """From 144 faces up the 29 stride-1 blocks of stage 3 run as ONE launch.  The two golden faces inside such a batch
+    """From 128 faces up the 29 stride-1 blocks of stage 3 run as ONE launch.  The two golden faces inside such a batch
     must meet north_star's bound against the fp32 oracle, and the whole batch must agree with the layer-by-layer path
     to f16 rounding noise (another f32 summation order: tap-major instead of chunk-major)."""
     d = golden("r100_kat.npz")
@@ -766,7 +766,7 @@ def test_r100_fp8_embedding_vs_golden(golden):
 
 
 def test_stage14_f8_path_equals_layer_path_and_meets_the_bound():
-    """From 144 faces up the fp8 convs of the 14x14 run execute as ONE launch (fr_conv_stage14_f8: codes resident in LDS,
+    """From 128 faces up the fp8 convs of the 14x14 run execute as ONE launch (fr_conv_stage14_f8: codes resident in LDS,
     residual stream through HBM).  Same arithmetic per conv as fr_conv_nhwc_f8, another summation order:
     (1) ONE block through the stage kernel equals the two per-layer fp8 convs to f16 rounding ties (the sharp check: rounding
     to e4m3 is discontinuous, so over 58 convs two valid summation orders drift apart by a good part of the fp8 noise
