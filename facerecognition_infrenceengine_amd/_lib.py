@@ -1,6 +1,7 @@
 """ctypes binding of libfrhip.so (include/frhip.h).  No CPU fallback: a missing library
 or a failing call raises."""
 import ctypes as C
+import struct
 import os
 import threading
 
@@ -36,7 +37,15 @@ class ConvF8Args(C.Structure):
                 ("bias_mode", C.c_int), ("y8_mul", C.c_float), ("y8_sub", C.c_void_p)]
 
 
+class Call(C.Structure):
+    """One recorded call of fr_detect_sequence: function id + arguments as 8-byte slots (include/frhip.h fr_call)."""
+    _fields_ = [("fn", C.c_int32), ("nargs", C.c_int32), ("a", C.c_uint64 * 22)]
+
+
 _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+# entry points fr_detect_sequence can replay (ids: include/frhip.h FR_FN_*)
+SEQ_FN = {"fr_dconv_mfma_f32": 1, "fr_pnet23_split_f16": 2, "fr_pnet_candidates": 3, "fr_sort_nms": 4, "fr_box_refine": 5,
+          "fr_crop_conv1_f32": 6, "fr_stage_select": 7}
 
 # name -> (restype, argtypes); every symbol include/frhip.h declares
 SIGNATURES = {
@@ -98,9 +107,21 @@ SIGNATURES = {
     "fr_box_refine": (_I, [_P, _P, _I, _P, _I, _I, _I, _P]),
     "fr_crop_resize_norm": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
     "fr_stage_select": (_I, [_P, _P, _I, _P, _I, _I, _F, _P, _P, _P, _I, _P, _P, _P]),
+    "fr_detect_sequence": (_I, [C.POINTER(Call), _I]),
 }
 
 _NOCHECK = ("fr_version", "fr_device_count")
+
+
+def _slot(v, t):
+    """a call argument as the 8-byte slot fr_detect_sequence reads"""
+    if t is _F:
+        return struct.unpack("<I", struct.pack("<f", float(v)))[0]
+    if t is _P:
+        if v is None:
+            return 0
+        return int(v.value or 0) if isinstance(v, C.c_void_p) else int(v)
+    return int(v) & 0xFFFFFFFFFFFFFFFF
 
 
 class Lib:
@@ -109,6 +130,7 @@ class Lib:
     def __init__(self, cdll):
         self._c = cdll
         self._calls = {}
+        self._rec = threading.local()          # .calls: a list while a thread records its detector calls (MTCNNHIP), else absent
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(cdll, name)      # AttributeError if the .so lacks a declared symbol
             fn.restype = res
@@ -121,12 +143,34 @@ class Lib:
     def _checked(self, name, fn):
         err = self._c.fr_last_error_string
 
+        fid, types, rec = SEQ_FN.get(name), fn.argtypes, self._rec
+
         def call(*a):
             rc = fn(*a)
             if rc != 0:
                 raise FrError(f"{name} failed ({rc}): {err().decode()}")
             return rc
-        return call
+
+        def call_rec(*a):                       # the same, and noted down when this thread is recording
+            rc = call(*a)
+            calls = getattr(rec, "calls", None)
+            if calls is not None:
+                calls.append((fid, [_slot(v, t) for v, t in zip(a, types)]))
+            return rc
+        return call_rec if fid is not None else call
+
+    def start_recording(self):
+        self._rec.calls = []
+
+    def note(self, fid, *slots):
+        """append a pseudo call (FR_FN_EVENT_RECORD = 8 / FR_FN_STREAM_WAIT = 9) to this thread's recording, if any"""
+        calls = getattr(self._rec, "calls", None)
+        if calls is not None:
+            calls.append((fid, [int(v.value or 0) if isinstance(v, C.c_void_p) else int(v) for v in slots]))
+
+    def stop_recording(self):
+        calls, self._rec.calls = getattr(self._rec, "calls", None), None
+        return calls
 
     def __getattr__(self, name):
         try:

@@ -6,6 +6,7 @@ counts, so a whole batch of frames runs without a host synchronisation.  Convent
 ordering, thresholds, capacities) are those written down in ``oracle/detect.py``.
 """
 import contextlib
+import ctypes
 import math
 import threading
 
@@ -157,6 +158,7 @@ class MTCNNHIP:
         self.refine_margin = 2e-3           # in logit units, ~200x the split-precision error
         self.refined_cells = None           # optional device int32[1]: cells re-evaluated exactly (diagnostics)
         self.p23_all_heads = False          # True: the fused kernel also writes the approximate heads of the cells it rules out
+        self.use_sequence = True            # eager single-frame calls of a known frame shape replay a recorded C call list (fr_detect_sequence)
         # first R-/O-Net layer fused with the crop (csrc/ro_conv1.hip): weights as [k = (kh, kw, channel)][cout]
         self.fused_crop = True
         self._rc1 = tuple(t.to(torch.float32).contiguous().to(d) for t in (
@@ -206,6 +208,7 @@ class MTCNNHIP:
         if i < len(lst) and lst[i].shape == tuple(shape) and lst[i].dtype == dtype:
             return lst[i]
         t = torch.empty(shape, dtype=dtype, device=self.device)
+        self._tls.cache_grew = True             # a recorded call list of this frame shape would hold stale pointers
         if i < len(lst):
             lst[i] = t
         else:
@@ -335,7 +338,9 @@ class MTCNNHIP:
         lib, t0, t1, t2 = self.lib, *self.thresholds
         with torch.cuda.device(self.device):
             self._s = _lib.stream_ptr()
-            self._tls.cache = None              # (a call that raised may have left it set)
+            self._tls.cache = None              # (a call that raised may have left these set)
+            self._tls.cache_grew = False
+            self.lib.stop_recording()
             self._mark("start")
             scales = pyramid_scales(H, W, self.minsize, self.factor)
             nlev = len(scales)
@@ -345,9 +350,7 @@ class MTCNNHIP:
                         torch.zeros(N, dtype=torch.int32, device=self.device))
             assert nlev * self.keep_scale <= 4096, "too many pyramid levels for the merged NMS list"
             cs = self.cap_scale
-            lb, ls, lr, lc = self._f32(nlev, N, cs, 4), self._f32(nlev, N, cs), self._f32(nlev, N, cs, 4), self._i32(nlev, N)
             ksz = self.keep_scale
-            kb, ks, ka, kc = self._f32(nlev, N, ksz, 4), self._f32(nlev, N, ksz), self._f32(nlev, N, ksz, 4), self._i32(nlev, N)
             # Level 0 holds half of the pyramid's pixels; the remaining levels are small launches that cannot fill
             # 256 CUs on their own, so they are dealt round-robin over side HIP streams beside level 0 (joined before
             # the NMS).
@@ -368,12 +371,45 @@ class MTCNNHIP:
             # An EAGER single-frame call is bound by the interpreter (host issue 0.73 ms against 0.85 ms until the GPU is done,
             # tools/host_time_c1.py): side streams would only add their fork / join events and a stream switch per level
             solo = trace is not None or self.one_stream or (N < 8 and level_streams is None and not torch.cuda.is_current_stream_capturing())
+            record = False
             if solo and trace is None and N < 8 and not torch.cuda.is_current_stream_capturing():
                 caches = self._tls.__dict__.setdefault("caches", {})
+                seqs = self._tls.__dict__.setdefault("seqs", {})
                 key = (N, H, W, main.cuda_stream)
                 if key not in caches and len(caches) >= 4:
-                    caches.pop(next(iter(caches)))                  # oldest frame shape of this thread
+                    old_key = next(iter(caches))                    # oldest frame shape of this thread
+                    caches.pop(old_key); seqs.pop(old_key, None)
+                known = key in caches
                 self._tls.cache = [caches.setdefault(key, []), 0]
+                # From the second call of a frame shape on every work tensor is the cached one of the call before, so the call
+                # is the same list of C calls with the same arguments - but for the frame and the four result tensors.  It is
+                # recorded once (third call: the second fills the cache) and replayed by ONE C call afterwards
+                # (fr_detect_sequence): the interpreter's ~50 ctypes calls were what an eager single-frame call waited for.
+                cfg = (self.fused_pnet, self.fused_crop, self.merged_level_nms, self.thresholds, self.p23_all_heads, self.refine_margin,
+                       self.cap_scale, self.keep_scale, self.cap_p, self.cap_r, self.cap_o, self.minsize, self.factor)
+                if self.use_sequence and self.phase_marks is None and self.refined_cells is None:
+                    seq = seqs.get(key)
+                    if seq is not None and seq["cfg"] == cfg:
+                        self._tls.cache = None
+                        return self._replay(seq, frames)
+                    record = known
+                    if record:
+                        lib.start_recording()
+                        # The recorded call deals the pyramid levels 1.. over side streams, forked from and joined to the
+                        # caller's stream by events of its own (the call list carries their record / wait): replayed by one
+                        # C call the host is no longer what the GPU waits for, the serial chain of ten levels is
+                        nrec = min(4, max(1, nlev - 1))
+                        while len(self._sides[main.cuda_stream]) < nrec:
+                            self._sides[main.cuda_stream].append(torch.cuda.Stream(device=self.device))
+                        rec_sides = self._sides[main.cuda_stream][:nrec]
+                        rec_events = [torch.cuda.Event() for _ in range(nrec + 1)]
+                        rec_events[0].record(main)
+                        lib.note(8, rec_events[0].cuda_event, main.cuda_stream)
+                        for side in rec_sides:
+                            side.wait_event(rec_events[0])
+                            lib.note(9, side.cuda_stream, rec_events[0].cuda_event)
+            lb, ls, lr, lc = self._f32(nlev, N, cs, 4), self._f32(nlev, N, cs), self._f32(nlev, N, cs, 4), self._i32(nlev, N)
+            kb, ks, ka, kc = self._f32(nlev, N, ksz, 4), self._f32(nlev, N, ksz), self._f32(nlev, N, ksz, 4), self._i32(nlev, N)
             if not solo:
                 for side in sides:
                     side.wait_stream(main)
@@ -382,6 +418,8 @@ class MTCNNHIP:
                 with (contextlib.nullcontext() if solo else torch.cuda.stream(main if li == 0 else side)):
                     if not solo:
                         self._s = _lib.stream_ptr()
+                    elif record:
+                        self._s = ctypes.c_void_p((main if li == 0 else rec_sides[(li - 1) % len(rec_sides)]).cuda_stream)
                     head, hc, wc = self.pnet_level(frames, s, trace)
                     nblk = -(-hc * wc // 256)
                     bc = self._i32(N * nblk)
@@ -401,6 +439,13 @@ class MTCNNHIP:
                 for side in sides:
                     main.wait_stream(side)
                 self._s = _lib.stream_ptr()
+            elif record:
+                for side, ev in zip(rec_sides, rec_events[1:]):
+                    ev.record(side)
+                    lib.note(8, ev.cuda_event, side.cuda_stream)
+                    main.wait_event(ev)
+                    lib.note(9, main.cuda_stream, ev.cuda_event)
+                self._s = ctypes.c_void_p(main.cuda_stream)
             self._mark("pnet")
             if N < 8 or self.merged_level_nms:
                 self._nms(lb, ls, lr, 4, lc, nlev * N, 1, cs, 0, 0.5, 0, ksz, out=(kb, ks, ka, kc))
@@ -449,6 +494,46 @@ class MTCNNHIP:
             self._mark("stage3")
             if trace is not None:
                 trace.update(onet_head=head3, onet_prob=prob3)
+            if record:
+                calls = lib.stop_recording()
+                if calls and not self._tls.cache_grew:
+                    seqs[key] = self._make_sequence(calls, frames, (b3, s3, a3, c3), cfg)
+                    seqs[key]["events"] = rec_events                 # the call list holds their handles
+            elif self._tls.cache_grew and getattr(self._tls, "seqs", None):
+                self._tls.seqs.pop((N, H, W, main.cuda_stream), None)
             # aux = (reg4, (x1,y1)..(x5,y5)): kps is a strided view, no copy
             kps = a3[..., 4:14].unflatten(-1, (5, 2))
         return b3, s3, kps, c3
+
+    def _make_sequence(self, calls, frames, outs, cfg):
+        """The recorded C calls of one eager single-frame detect_batch as an fr_call array, with the argument slots that held
+        the frame's pointer and the four result tensors' pointers noted: those are patched per call."""
+        arr = (_lib.Call * len(calls))()
+        fptr = frames.data_ptr()
+        optr = {t.data_ptr(): i for i, t in enumerate(outs)}
+        fpos, opos = [], [[] for _ in outs]
+        for k, (fid, slots) in enumerate(calls):
+            arr[k].fn, arr[k].nargs = fid, len(slots)
+            for i, v in enumerate(slots):
+                arr[k].a[i] = v
+                if v == fptr:
+                    fpos.append((k, i))
+                elif v in optr:
+                    opos[optr[v]].append((k, i))
+        assert fpos and all(opos), "the recorded detector call list must mention the frame and every result tensor"
+        return {"arr": arr, "n": len(calls), "fpos": fpos, "opos": opos, "cfg": cfg,
+                "meta": [(tuple(t.shape), t.dtype) for t in outs]}
+
+    def _replay(self, seq, frames):
+        arr = seq["arr"]
+        outs = [torch.empty(shape, dtype=dtype, device=self.device) for shape, dtype in seq["meta"]]
+        fptr = frames.data_ptr()
+        for k, i in seq["fpos"]:
+            arr[k].a[i] = fptr
+        for t, pos in zip(outs, seq["opos"]):
+            p = t.data_ptr()
+            for k, i in pos:
+                arr[k].a[i] = p
+        self.lib.fr_detect_sequence(arr, seq["n"])
+        b3, s3, a3, c3 = outs
+        return b3, s3, a3[..., 4:14].unflatten(-1, (5, 2)), c3

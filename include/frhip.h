@@ -379,6 +379,21 @@ int fr_stage_select(const float* boxes, const float* head, int nh, const int32_t
                     float thr, float* boxes_out, float* scores_out, float* aux_out, int naux,
                     int32_t* counts_out, float* prob_out, fr_stream_t stream);
 
+/* A recorded run of detector calls replayed by ONE C call (an eager single-frame get() is bound by the interpreter: ~50
+ * ctypes calls per frame; FaceAnalysis.get, infrenceServer.py:528).  `fn` names the entry point, `a` carries its arguments
+ * as 8-byte slots in declaration order: pointers and size_t as they are, ints sign-extended, floats as their IEEE bits in
+ * the low word.  Two further ids record / wait for an event of the CALLER's (no allocation here): a recorded call may deal
+ * the pyramid levels over side streams.  Same kernels, same order per stream, same bits as the individual calls; stops at
+ * the first failing call. */
+enum { FR_FN_DCONV_MFMA = 1, FR_FN_PNET23 = 2, FR_FN_PNET_CANDIDATES = 3, FR_FN_SORT_NMS = 4, FR_FN_BOX_REFINE = 5,
+       FR_FN_CROP_CONV1 = 6, FR_FN_STAGE_SELECT = 7,
+       FR_FN_EVENT_RECORD = 8 /* a = (hipEvent_t, hipStream_t) */, FR_FN_STREAM_WAIT = 9 /* a = (hipStream_t, hipEvent_t) */ };
+typedef struct {
+    int32_t fn; int32_t nargs;
+    uint64_t a[22];
+} fr_call;
+int fr_detect_sequence(const fr_call* calls, int ncalls);
+
 #ifdef __cplusplus
 }
 #endif

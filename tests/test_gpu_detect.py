@@ -273,6 +273,53 @@ def test_fused_pnet_exact_pass_with_every_cell_on_its_work_list():
     assert int(fused.refined_cells[0]) == 2 * listed
 
 
+def test_eager_single_frame_call_list_equals_launch_by_launch():
+    """An eager single-frame detect_batch of a frame shape seen twice before replays ONE recorded C call list
+    (fr_detect_sequence, MTCNNHIP.use_sequence): same kernels, same arguments - but for the frame and the four result tensors,
+    which are patched in - so boxes / scores / landmarks / counts equal the launch-by-launch call bit for bit, frame after
+    frame, across a change of frame shape and back, and after a threshold changed (a new recording)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import synth_frame
+    from facerecognition_infrenceengine_amd import weights
+    from facerecognition_infrenceengine_amd.mtcnn import MTCNNHIP
+    st = weights.synth_mtcnn_states(seed=4321)
+    seq = MTCNNHIP(*st, device="cuda:0")
+    ref = MTCNNHIP(*st, device="cuda:0")
+    ref.use_sequence = False
+
+    def same(hw, seed):
+        fr = torch.from_numpy(synth_frame(hw[0], hw[1], seed)[None]).cuda()
+        a, b = seq.detect_batch(fr), ref.detect_batch(fr)
+        torch.cuda.synchronize()
+        assert torch.equal(a[3], b[3]) and int(a[3][0]) >= 1
+        n = int(a[3][0])
+        for x, y in zip(a[:3], b[:3]):
+            assert torch.equal(x[0, :n], y[0, :n])
+        return a
+
+    kept = [same((240, 320), s) for s in range(20, 26)]            # calls 1, 2: eager (cache fill, recording); 3 ..: replayed
+    assert len(seq._tls.seqs) == 1
+    first = [t.clone() for t in kept[3]]
+    for s in range(30, 33):
+        same((200, 264), s)                                       # another frame shape: its own cache and list
+    same((240, 320), 40)                                          # back: the first list is still valid
+    assert all(torch.equal(x, y) for x, y in zip(first, kept[3])) # results handed out earlier were not overwritten
+    assert len(seq._tls.seqs) == 2
+    seq.thresholds = ref.thresholds = (0.6, 0.7, 0.75)            # a configuration change invalidates the recorded list
+    for s in range(50, 54):
+        same((240, 320), s)
+    # two frames at once (still a single-frame-mode batch): lists are per batch shape
+    fr2 = torch.from_numpy(np.stack([synth_frame(240, 320, 60), synth_frame(240, 320, 61)])).cuda()
+    for _ in range(4):
+        a, b = seq.detect_batch(fr2), ref.detect_batch(fr2)
+        assert torch.equal(a[3], b[3])
+        for f in range(2):
+            n = int(a[3][f])
+            for x, y in zip(a[:3], b[:3]):
+                assert torch.equal(x[f, :n], y[f, :n])
+
+
 @pytest.mark.parametrize("negative_slopes", [False, True])
 def test_pnet_conv1_kernel_vs_oracle_and_16x16x4_form(negative_slopes):
     """P-Net conv1 (+ pyramid resize, PReLU, 2x2 ceil pool) runs as its own 4x4x1-MFMA kernel (csrc/pnet_conv1.hip).
