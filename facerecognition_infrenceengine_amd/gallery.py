@@ -6,12 +6,15 @@ of a row-indexed ``[N,512]`` matrix.  Row order = insertion order of the referen
 dict (employees in cursor order, then visitors: infrenceServer.py:264,288); the winner is
 the maximum score, lowest row on exact ties (strict ``>`` in the reference loop).
 """
+import threading
+
 import numpy as np
 import torch
 
 from . import _lib
 
 DIM = 512
+_PIN = threading.local()       # pinned host buffers of GalleryMatcher.match, per thread and query count
 
 
 class StaleViewError(_lib.FrError):
@@ -117,7 +120,20 @@ class GalleryMatcher:
         Q = torch.as_tensor(np.asarray(Q, np.float32)) if not torch.is_tensor(Q) else Q
         idx, score = self.match_device(Q)
         dec = self.decide_device(idx, score, thr, unknown_thr)
-        idx_h, score_h, dec_h = idx.cpu().numpy(), score.cpu().numpy(), dec.cpu().numpy()
+        # three results, ONE synchronisation: asynchronous copies into pinned host memory, then a stream sync
+        F = idx.shape[0]
+        pin = _PIN.__dict__.setdefault("bufs", {})          # per thread: match() may be called by several on one matcher
+        h = pin.get(F)
+        if h is None:
+            if len(pin) >= 16:
+                pin.clear()
+            h = pin[F] = (torch.empty(F, dtype=torch.int64).pin_memory(), torch.empty(F, dtype=torch.float32).pin_memory(),
+                          torch.empty(F, dtype=torch.int32).pin_memory())
+        with torch.cuda.device(self.device):
+            for dst, src in zip(h, (idx, score, dec)):
+                dst.copy_(src, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        idx_h, score_h, dec_h = h[0].numpy().copy(), h[1].numpy().copy(), h[2].numpy().copy()
         ids = [self.ids[i] if (d == 1 and i >= 0) else None for i, d in zip(idx_h, dec_h)]
         return ids, score_h, idx_h
 
