@@ -383,7 +383,7 @@ class MTCNNHIP:
                 self._tls.cache = [caches.setdefault(key, []), 0]
                 # From the second call of a frame shape on every work tensor is the cached one of the call before, so the call
                 # is the same list of C calls with the same arguments - but for the frame and the four result tensors.  It is
-                # recorded once (third call: the second fills the cache) and replayed by ONE C call afterwards
+                # recorded once (on the second call: the first filled the cache) and replayed by ONE C call from the third on
                 # (fr_detect_sequence): the interpreter's ~50 ctypes calls were what an eager single-frame call waited for.
                 cfg = (self.fused_pnet, self.fused_crop, self.merged_level_nms, self.thresholds, self.p23_all_heads, self.refine_margin,
                        self.cap_scale, self.keep_scale, self.cap_p, self.cap_r, self.cap_o, self.minsize, self.factor)
