@@ -39,17 +39,35 @@ __global__ __launch_bounds__(NMS_T) void sort_nms(const float* __restrict__ boxe
     // index as the tie-break), then a bitonic sort of the next power of two above their number - not of the lists'
     // capacity: a single frame's merged per-level lists (20 480 slots, a few hundred entries) sorted 2 048 + 4 096 keys in
     // 51 + 77 us.  One LDS atomic per wave and pass.
-    for (int i0 = 0; i0 < NP; i0 += NMS_T) {
-        const int i = i0 + tid;
-        unsigned long long k = 0ull;
+    // (the passes' loads first - segment counts, then scores: two round trips for the whole list instead of two per pass)
+    constexpr int NPASS = NMAX / NMS_T;
+    int cnt[NPASS];
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+        const int i = q * NMS_T + tid;
+        cnt[q] = 0;
         if (i < ntot) {
-            int s = i / seg_cap, j = i - s * seg_cap;
-            int64_t seg = seg_major ? (int64_t)s * L + l : (int64_t)l * nseg + s;
-            if (j < counts[seg]) {
-                unsigned sb_ = __float_as_uint(scores[seg * seg_cap + j]);
-                k = ((unsigned long long)sb_ << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+            const int s = i / seg_cap;
+            cnt[q] = counts[seg_major ? (int64_t)s * L + l : (int64_t)l * nseg + s];
+        }
+    }
+    unsigned long long kk[NPASS];
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+        const int i = q * NMS_T + tid;
+        kk[q] = 0ull;
+        if (i < ntot) {
+            const int s = i / seg_cap, j = i - s * seg_cap;
+            if (j < cnt[q]) {
+                const int64_t seg = seg_major ? (int64_t)s * L + l : (int64_t)l * nseg + s;
+                kk[q] = ((unsigned long long)__float_as_uint(scores[seg * seg_cap + j]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
             }
         }
+    }
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+        if (q * NMS_T >= NP) break;                          // uniform: the list's capacity rounds up to fewer passes
+        const unsigned long long k = kk[q];
         // a valid key is never 0: its low word is 0xFFFFFFFF - i with i < 4096
         const unsigned long long bal = __ballot(k != 0ull);
         if (bal) {
