@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libfrhip.so")
 
 _lock = threading.Lock()
 _lib = None
+ABI_VERSION = 102          # include/frhip.h FR_ABI_VERSION this binding was written against (tests/test_abi.py compares)
 
 
 class FrError(RuntimeError):
@@ -35,6 +36,13 @@ class ConvF8Args(C.Structure):
                 ("oscale", C.c_void_p), ("bias", C.c_void_p), ("slope", C.c_void_p), ("residual", C.c_void_p),
                 ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
                 ("bias_mode", C.c_int), ("y8_mul", C.c_float), ("y8_sub", C.c_void_p)]
+
+
+class RolePtr(C.c_void_p):
+    """A device pointer whose ROLE in a recorded detector call list is known where it is passed (``ptr(t, role=...)``):
+    the recorder notes the role beside the slot, and a replay patches exactly the slots that were recorded with a
+    role - the frame and the four result tensors - never a slot that merely holds the same address."""
+    role = None
 
 
 class Call(C.Structure):
@@ -149,28 +157,43 @@ class Lib:
             rc = fn(*a)
             if rc != 0:
                 raise FrError(f"{name} failed ({rc}): {err().decode()}")
+            if getattr(rec, "calls", None) is not None:
+                # a launch the call list cannot express (fr_detect_sequence replays SEQ_FN only): a replay would skip
+                # it and the kernels behind it would read what an earlier frame left in the work tensors
+                rec.invalid = name
             return rc
 
-        def call_rec(*a):                       # the same, and noted down when this thread is recording
-            rc = call(*a)
+        def call_rec(*a):                       # noted down when this thread is recording: (id, slots, [(slot, role)])
+            rc = fn(*a)
+            if rc != 0:
+                raise FrError(f"{name} failed ({rc}): {err().decode()}")
             calls = getattr(rec, "calls", None)
             if calls is not None:
-                calls.append((fid, [_slot(v, t) for v, t in zip(a, types)]))
+                calls.append((fid, [_slot(v, t) for v, t in zip(a, types)],
+                              [(i, v.role) for i, v in enumerate(a) if isinstance(v, RolePtr)]))
             return rc
         return call_rec if fid is not None else call
 
     def start_recording(self):
-        self._rec.calls = []
+        self._rec.calls, self._rec.invalid = [], None
 
     def note(self, fid, *slots):
         """append a pseudo call (FR_FN_EVENT_RECORD = 8 / FR_FN_STREAM_WAIT = 9) to this thread's recording, if any"""
         calls = getattr(self._rec, "calls", None)
         if calls is not None:
-            calls.append((fid, [int(v.value or 0) if isinstance(v, C.c_void_p) else int(v) for v in slots]))
+            calls.append((fid, [int(v.value or 0) if isinstance(v, C.c_void_p) else int(v) for v in slots], []))
 
     def stop_recording(self):
+        """The recorded calls, or None when nothing was recorded or the recording is unusable: an entry point outside
+        SEQ_FN was called meanwhile (``recording_invalid()`` names it)."""
         calls, self._rec.calls = getattr(self._rec, "calls", None), None
-        return calls
+        self._rec.last_invalid = getattr(self._rec, "invalid", None)
+        self._rec.invalid = None
+        return None if self._rec.last_invalid else calls
+
+    def recording_invalid(self):
+        """name of the entry point that made this thread's last recording unusable, or None"""
+        return getattr(self._rec, "last_invalid", None)
 
     def __getattr__(self, name):
         try:
@@ -200,16 +223,27 @@ def load():
             if not os.path.exists(LIB_PATH):
                 raise FrError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               f"or `make -C {os.path.dirname(LIB_PATH)}`; there is no CPU fallback")
-            _lib = Lib(C.CDLL(LIB_PATH))
+            lib = Lib(C.CDLL(LIB_PATH))
+            have = lib.fr_version()
+            if have != ABI_VERSION:     # a stale .so: argument structs / signatures of another shape
+                raise FrError(f"{LIB_PATH} implements ABI version {have}, this binding needs {ABI_VERSION}: rebuild it "
+                              f"(`make -C {os.path.dirname(LIB_PATH)}`)")
+            _lib = lib
         return _lib
 
 
-def ptr(t):
-    """Device pointer of a torch tensor (or None).  The pointer does not keep the tensor alive: pass NAMED tensors.
+def ptr(t, role=None):
+    """Device pointer of a torch tensor (or None); ``role``: see RolePtr.  The pointer does not keep the tensor alive: pass NAMED tensors.
     ``ptr(x[sel].contiguous())`` written inline frees the temporary as soon as the pointer is taken, and a second
     temporary built for the next argument of the same call can be handed the same block - its producer kernel is
     then queued BEFORE the consumer and overwrites the data (found the hard way: face_analysis.py compact_embed)."""
-    return None if t is None else C.c_void_p(t.data_ptr())
+    if t is None:
+        return None
+    if role is None:
+        return C.c_void_p(t.data_ptr())
+    p = RolePtr(t.data_ptr())
+    p.role = role
+    return p
 
 
 def stream_ptr():

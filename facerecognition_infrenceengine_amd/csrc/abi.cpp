@@ -11,7 +11,7 @@ void fr_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int fr_version(void) { return 100; }
+extern "C" int fr_version(void) { return FR_ABI_VERSION; }
 extern "C" const char* fr_last_error_string(void) { return g_err; }
 extern "C" int fr_device_count(void) {
     int n = 0;
@@ -29,6 +29,14 @@ inline float sf(const fr_call& c, int i) { union { uint32_t b; float f; } u; u.b
 }
 extern "C" int fr_detect_sequence(const fr_call* calls, int ncalls) {
     FR_REQUIRE(calls && ncalls > 0, "fr_detect_sequence: no calls");
+    // arity of every entry first: nothing is launched from a list that holds a short or malformed call
+    static const int arity[10] = {-1, 18, 20, 16, 18, 8, 13, 14, 2, 2};
+    for (int k = 0; k < ncalls; ++k) {
+        const int fn = calls[k].fn;
+        FR_REQUIRE(fn >= 1 && fn <= 9, "fr_detect_sequence: call %d: unknown function id %d", k, fn);
+        FR_REQUIRE(calls[k].nargs == arity[fn], "fr_detect_sequence: call %d (function id %d): %d arguments, expected %d", k, fn,
+                   calls[k].nargs, arity[fn]);
+    }
     for (int k = 0; k < ncalls; ++k) {
         const fr_call& c = calls[k];
         int rc;

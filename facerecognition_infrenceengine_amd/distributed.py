@@ -141,6 +141,24 @@ class ShardedGalleryMatcher:
         self.force_exchange = force_exchange
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.timing = None          # a list: every exchange appends its five HIP events (bench.py's exchange_ms; diagnostics)
+
+    def _stamp(self, marks, dev):
+        if marks is not None and dev.type == "cuda":
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream(dev))
+            marks.append(e)
+
+    def exchange_ms(self):
+        """Median milliseconds of the exchange's four parts over the matches timed since ``timing = []`` was set (the caller
+        synchronises first): gather_q = pack + the all-gather of the query rows (includes waiting for the slowest rank's
+        embedder), scan = count row + this rank's shard scan, gather_c = pack + the all-gather of the candidates,
+        reduce.  None when nothing was timed."""
+        rows = [[m[k].elapsed_time(m[k + 1]) for k in range(4)] for m in (self.timing or []) if len(m) == 5]
+        if not rows:
+            return None
+        med = torch.tensor(rows, dtype=torch.float64).median(dim=0).values.tolist()
+        return {k: round(v, 4) for k, v in zip(("gather_q", "scan", "gather_c", "reduce"), med)} | {"samples": len(rows)}
 
     def match(self, Q):
         """Q f32 [F_local,dim] ``normed_embedding`` rows on this rank's device (F_local <= q_max).
@@ -152,17 +170,26 @@ class ShardedGalleryMatcher:
             return self.ops.scan(Qn)
         dev = Q.device
         seg = self.q_max + 1
+        marks = [] if self.timing is not None else None
+        self._stamp(marks, dev)
         # (1) gather queries; the count rides in an extra row so it stays ONE collective
         send = self.ops.pack_queries(Qn, self.q_max)
         allq = torch.empty((self.world * seg, self.dim), dtype=torch.float32, device=dev)
         dist.all_gather_into_tensor(allq, send, group=self.group)      # concatenated along dim 0
+        self._stamp(marks, dev)
         counts = self.ops.gathered_counts(allq, self.world, self.q_max)   # gathered face counts, on the device
         # (2) scan the local shard for every gathered query slot IN PLACE: a rank's segment is its q_max query slots +
         # the count row, which is slot q_max >= count, i.e. padding like every slot past the count (skipped by the scan)
         idx, score = self.ops.scan(allq, counts=counts, seg_len=seg)
+        self._stamp(marks, dev)
         # (3) gather the per-shard candidates and reduce those of the local queries
         n = score.shape[0]
         pair = self.ops.pack(idx, score)
         allp = torch.empty((self.world * n, 3), dtype=torch.int32, device=dev)
         dist.all_gather_into_tensor(allp, pair, group=self.group)
-        return self.ops.reduce(allp, self.world, n, self.rank * seg, F)
+        self._stamp(marks, dev)
+        out = self.ops.reduce(allp, self.world, n, self.rank * seg, F)
+        self._stamp(marks, dev)
+        if marks:
+            self.timing.append(marks)
+        return out

@@ -221,13 +221,18 @@ class MTCNNHIP:
     def _i32(self, *shape):
         return self._new(shape, torch.int32)
 
+    def _fptr(self, frames):
+        """The frame batch's pointer, tagged with its role for the call recorder (_lib.RolePtr): a replayed call list
+        patches exactly the slots recorded through here."""
+        return _lib.ptr(frames, role="frame")
+
     def _dconv(self, x, c, B, H, W, frames=None, counts=None, cap=0, y_split=None):
         ho, wo = c.out_hw(H, W)
         y = self._f32(B, ho, wo, c.nhead if c.nhead else c.cout)
         if isinstance(c, _MConv):
             fh, fw = (frames.shape[1], frames.shape[2]) if frames is not None else (0, 0)
             self.lib.fr_dconv_mfma_f32(c.layer, _lib.ptr(x), _lib.ptr(c.w), _lib.ptr(c.b), _lib.ptr(c.slope), _lib.ptr(y),
-                                       B, H, W, _lib.ptr(c.head_w), _lib.ptr(c.head_b), _lib.ptr(frames), fh, fw,
+                                       B, H, W, _lib.ptr(c.head_w), _lib.ptr(c.head_b), self._fptr(frames), fh, fw,
                                        _lib.ptr(counts), cap, _lib.ptr(y_split), self._s)
         else:
             self.lib.fr_dconv_f32(_lib.ptr(x), _lib.ptr(c.w), _lib.ptr(c.b), _lib.ptr(c.slope), _lib.ptr(y), B, H, W,
@@ -241,15 +246,17 @@ class MTCNNHIP:
         self.lib.fr_maxpool_f32(_lib.ptr(x), _lib.ptr(y), B, H, W, C, k, s, self._s)
         return y, ho, wo
 
-    def _nms(self, boxes, scores, aux, naux, counts, L, nseg, seg_cap, seg_major, thr, mode, keep, out=None):
+    def _nms(self, boxes, scores, aux, naux, counts, L, nseg, seg_cap, seg_major, thr, mode, keep, out=None, results=False):
+        """results: the four outputs are what detect_batch returns - their pointers carry the roles "out0".."out3" for the
+        call recorder."""
         if out is None:
             bo, so, co = self._f32(L, keep, 4), self._f32(L, keep), self._i32(L)
             ao = self._f32(L, keep, max(naux, 1))
         else:
             bo, so, ao, co = out
+        po = [_lib.ptr(t, role="out%d" % i if results else None) for i, t in enumerate((bo, so, ao, co))]
         self.lib.fr_sort_nms(_lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(aux), naux, _lib.ptr(counts), L, nseg, seg_cap,
-                             seg_major, thr, mode, keep, _lib.ptr(bo), _lib.ptr(so), _lib.ptr(ao), _lib.ptr(co), keep,
-                             self._s)
+                             seg_major, thr, mode, keep, *po, keep, self._s)
         return bo, so, ao, co
 
     # ---- nets
@@ -282,7 +289,7 @@ class MTCNNHIP:
         w, b, s = self._rc1 if net == 0 else self._oc1
         p, c = (11, 28) if net == 0 else (23, 32)
         y = self._f32(N * cap, p, p, c)
-        self.lib.fr_crop_conv1_f32(net, _lib.ptr(frames), N, H, W, _lib.ptr(boxes), _lib.ptr(counts), cap, _lib.ptr(w),
+        self.lib.fr_crop_conv1_f32(net, self._fptr(frames), N, H, W, _lib.ptr(boxes), _lib.ptr(counts), cap, _lib.ptr(w),
                                    _lib.ptr(b), _lib.ptr(s), _lib.ptr(y), self._s)
         return y
 
@@ -387,9 +394,18 @@ class MTCNNHIP:
                 # (fr_detect_sequence): the interpreter's ~50 ctypes calls were what an eager single-frame call waited for.
                 cfg = (self.fused_pnet, self.fused_crop, self.merged_level_nms, self.thresholds, self.p23_all_heads, self.refine_margin,
                        self.cap_scale, self.keep_scale, self.cap_p, self.cap_r, self.cap_o, self.minsize, self.factor)
-                if self.use_sequence and self.phase_marks is None and self.refined_cells is None:
-                    seq = seqs.get(key)
-                    if seq is not None and seq["cfg"] == cfg:
+                # Only the default configuration is recorded: fr_detect_sequence replays the entry points of _lib.SEQ_FN, and
+                # the stand-alone crop / the f32 P-Net layers on generic shapes go through others (the recorder refuses
+                # such a list as well: Lib.stop_recording); ``one_stream`` asks for every level on the caller's stream,
+                # which a recorded list (levels on side streams) would not honour.
+                seq_ok = (self.use_sequence and self.phase_marks is None and self.refined_cells is None and self.fused_pnet
+                          and self.fused_crop and not self.one_stream)
+                seq = seqs.get(key)
+                if seq is not None and (not seq_ok or seq["cfg"] != cfg):
+                    seqs.pop(key)                  # recorded under another configuration: never replayed again
+                    seq = None
+                if seq_ok:
+                    if seq is not None:
                         self._tls.cache = None
                         return self._replay(seq, frames)
                     record = known
@@ -462,7 +478,7 @@ class MTCNNHIP:
                 head2 = self.rnet(None, B2, c1, self.cap_p, x1=self.crop_conv1(0, frames, b1, c1, self.cap_p))
             else:
                 crops = self._f32(B2, 24, 24, 4)
-                lib.fr_crop_resize_norm(_lib.ptr(frames), N, H, W, _lib.ptr(b1), _lib.ptr(c1), self.cap_p, 24,
+                lib.fr_crop_resize_norm(self._fptr(frames), N, H, W, _lib.ptr(b1), _lib.ptr(c1), self.cap_p, 24,
                                         _lib.ptr(crops), self._s)
                 head2 = self.rnet(crops, B2, c1, self.cap_p)
             sb, ss, sa, sc = self._f32(N, self.cap_p, 4), self._f32(N, self.cap_p), self._f32(N, self.cap_p, 4), self._i32(N)
@@ -481,7 +497,7 @@ class MTCNNHIP:
                 head3 = self.onet(None, B3, c2, self.cap_r, x1=self.crop_conv1(1, frames, b2, c2, self.cap_r))
             else:
                 crops3 = self._f32(B3, 48, 48, 4)
-                lib.fr_crop_resize_norm(_lib.ptr(frames), N, H, W, _lib.ptr(b2), _lib.ptr(c2), self.cap_r, 48,
+                lib.fr_crop_resize_norm(self._fptr(frames), N, H, W, _lib.ptr(b2), _lib.ptr(c2), self.cap_r, 48,
                                         _lib.ptr(crops3), self._s)
                 head3 = self.onet(crops3, B3, c2, self.cap_r)
             tb, ts, ta, tc = self._f32(N, self.cap_r, 4), self._f32(N, self.cap_r), self._f32(N, self.cap_r, 14), self._i32(N)
@@ -490,36 +506,43 @@ class MTCNNHIP:
                                 _lib.ptr(ts), _lib.ptr(ta), 14, _lib.ptr(tc), _lib.ptr(prob3), self._s)
             lib.fr_box_refine(_lib.ptr(tb), _lib.ptr(ta), 14, _lib.ptr(tc), N, self.cap_r, 2, self._s)
             self._tls.cache = None                      # what is returned to the caller is never a cached work tensor
-            b3, s3, a3, c3 = self._nms(tb, ts, ta, 14, tc, N, 1, self.cap_r, 0, 0.7, 1, self.cap_o)
+            b3, s3, a3, c3 = self._nms(tb, ts, ta, 14, tc, N, 1, self.cap_r, 0, 0.7, 1, self.cap_o, results=True)
             self._mark("stage3")
             if trace is not None:
                 trace.update(onet_head=head3, onet_prob=prob3)
             if record:
-                calls = lib.stop_recording()
+                calls = lib.stop_recording()         # None: a launch the list cannot express happened (Lib.recording_invalid)
                 if calls and not self._tls.cache_grew:
                     seqs[key] = self._make_sequence(calls, frames, (b3, s3, a3, c3), cfg)
                     seqs[key]["events"] = rec_events                 # the call list holds their handles
-            elif self._tls.cache_grew and getattr(self._tls, "seqs", None):
+            if self._tls.cache_grew and getattr(self._tls, "seqs", None):
+                # a work tensor was replaced in this call (recording or not): a list recorded earlier for this frame shape
+                # holds the freed tensor's pointer
                 self._tls.seqs.pop((N, H, W, main.cuda_stream), None)
             # aux = (reg4, (x1,y1)..(x5,y5)): kps is a strided view, no copy
             kps = a3[..., 4:14].unflatten(-1, (5, 2))
         return b3, s3, kps, c3
 
     def _make_sequence(self, calls, frames, outs, cfg):
-        """The recorded C calls of one eager single-frame detect_batch as an fr_call array, with the argument slots that held
-        the frame's pointer and the four result tensors' pointers noted: those are patched per call."""
+        """The recorded C calls of one eager single-frame detect_batch as an fr_call array.  The slots a replay patches -
+        the frame and the four result tensors - are those the call sites passed WITH that role (_lib.RolePtr: ``_fptr``,
+        ``_nms(results=True)``), noted by the recorder beside the call; no slot is found by comparing pointer values.  The
+        values only serve as a check: a slot that holds the frame's or a result's address without the role would be a
+        call site that forgot it, and the list is refused."""
         arr = (_lib.Call * len(calls))()
-        fptr = frames.data_ptr()
-        optr = {t.data_ptr(): i for i, t in enumerate(outs)}
+        want = {"frame": frames.data_ptr(), **{"out%d" % i: t.data_ptr() for i, t in enumerate(outs)}}
         fpos, opos = [], [[] for _ in outs]
-        for k, (fid, slots) in enumerate(calls):
+        for k, (fid, slots, roles) in enumerate(calls):
             arr[k].fn, arr[k].nargs = fid, len(slots)
             for i, v in enumerate(slots):
                 arr[k].a[i] = v
-                if v == fptr:
-                    fpos.append((k, i))
-                elif v in optr:
-                    opos[optr[v]].append((k, i))
+            tagged = dict(roles)
+            for i, role in roles:
+                assert slots[i] == want[role], f"call {k}: slot {i} was recorded as '{role}' but holds another tensor"
+                (fpos if role == "frame" else opos[int(role[3:])]).append((k, i))
+            if fid < 8:                              # (event / stream handles of the pseudo calls are not tensors)
+                for i, v in enumerate(slots):
+                    assert i in tagged or v not in want.values(), f"call {k}: slot {i} holds a patched tensor without its role"
         assert fpos and all(opos), "the recorded detector call list must mention the frame and every result tensor"
         return {"arr": arr, "n": len(calls), "fpos": fpos, "opos": opos, "cfg": cfg,
                 "meta": [(tuple(t.shape), t.dtype) for t in outs]}

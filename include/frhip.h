@@ -32,6 +32,10 @@ extern "C" {
 
 typedef void* fr_stream_t;
 
+/* Version of THIS header's ABI: bumped whenever a signature or an argument struct changes shape (101: fr_conv_args gained
+ * x2 / C2, fr_conv_f8_args y8_sub, fr_pnet23_split_f16 all_heads).  fr_version() returns the value the library was built
+ * with: a caller compiled against another header must refuse to go on (the Python binding does, _lib.load()). */
+#define FR_ABI_VERSION 102
 int fr_version(void);
 const char* fr_last_error_string(void);
 /* number of visible HIP devices (<=0: none); does not create a context on any device */
@@ -384,7 +388,8 @@ int fr_stage_select(const float* boxes, const float* head, int nh, const int32_t
  * as 8-byte slots in declaration order: pointers and size_t as they are, ints sign-extended, floats as their IEEE bits in
  * the low word.  Two further ids record / wait for an event of the CALLER's (no allocation here): a recorded call may deal
  * the pyramid levels over side streams.  Same kernels, same order per stream, same bits as the individual calls; stops at
- * the first failing call. */
+ * the first failing call.  `nargs` must be the entry point's arity (18 / 20 / 16 / 18 / 8 / 13 / 14, 2 for the event ids):
+ * a short or malformed entry is refused before anything is launched. */
 enum { FR_FN_DCONV_MFMA = 1, FR_FN_PNET23 = 2, FR_FN_PNET_CANDIDATES = 3, FR_FN_SORT_NMS = 4, FR_FN_BOX_REFINE = 5,
        FR_FN_CROP_CONV1 = 6, FR_FN_STAGE_SELECT = 7,
        FR_FN_EVENT_RECORD = 8 /* a = (hipEvent_t, hipStream_t) */, FR_FN_STREAM_WAIT = 9 /* a = (hipStream_t, hipEvent_t) */ };

@@ -28,7 +28,9 @@ def test_header_symbols_exported_and_bound():
     for s in _lib.SIGNATURES:
         assert s in syms, f"{s} bound but not declared in frhip.h"
     lib = _lib.load()
-    assert lib.fr_version() >= 100
+    # the binding, the header and the built library agree on the ABI version (a stale .so is refused by _lib.load())
+    macro = int(re.search(r"#define FR_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "frhip.h")).read()).group(1))
+    assert lib.fr_version() == macro == _lib.ABI_VERSION
 
 
 def test_invalid_arguments_return_error_not_crash():
@@ -77,6 +79,13 @@ def test_call_list_entry_layout_and_slots():
     bad[0].fn = 99
     with pytest.raises(_lib.FrError, match="unknown function id"):
         lib.fr_detect_sequence(bad, 1)
+    # an entry's nargs must be its entry point's arity: checked for the WHOLE list before anything is launched
+    for name, fid in _lib.SEQ_FN.items():
+        two = (_lib.Call * 2)()
+        two[0].fn, two[0].nargs = 8, 2                    # a well-formed event record in front (never executed)
+        two[1].fn, two[1].nargs = fid, len(_lib.SIGNATURES[name][1]) - 1
+        with pytest.raises(_lib.FrError, match=r"call 1 .*arguments, expected %d" % len(_lib.SIGNATURES[name][1])):
+            lib.fr_detect_sequence(two, 2)
 
 
 def test_device_code_has_no_packed_f32_ops(tmp_path):

@@ -320,6 +320,81 @@ def test_eager_single_frame_call_list_equals_launch_by_launch():
                 assert torch.equal(x[f, :n], y[f, :n])
 
 
+def test_call_list_is_rerecorded_when_thresholds_or_caps_change_and_never_covers_other_entry_points():
+    """Guards of the recorded call list: (i) ``thresholds`` and ``cap_o`` changed between two
+    calls of ONE frame shape: the old list is dropped on the spot and a new one recorded - results keep following the
+    launch-by-launch engine bit for bit, and the result tensors take the new ``cap_o`` shape; (ii) with ``fused_crop = False``
+    the cascade launches fr_crop_resize_norm, which fr_detect_sequence cannot replay: nothing is recorded, four and more
+    calls stay equal to ``use_sequence = False`` (a replay that skipped the crops would hand R-/O-Net the PREVIOUS
+    frame's crops); switching the attribute back records afresh; (iii) a recording during which an entry point outside
+    _lib.SEQ_FN is called is refused by the recorder itself; (iv) ``one_stream`` calls are never replayed."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import synth_frame
+    from facerecognition_infrenceengine_amd import _lib, weights
+    from facerecognition_infrenceengine_amd.mtcnn import MTCNNHIP
+    st = weights.synth_mtcnn_states(seed=4321)
+    seq = MTCNNHIP(*st, device="cuda:0")
+    ref = MTCNNHIP(*st, device="cuda:0")
+    ref.use_sequence = False
+    replays = []
+    orig = seq._replay
+    seq._replay = lambda s, f: (replays.append(1), orig(s, f))[1]
+
+    def same(seed, hw=(240, 320)):
+        fr = torch.from_numpy(synth_frame(hw[0], hw[1], seed)[None]).cuda()
+        a, b = seq.detect_batch(fr), ref.detect_batch(fr)
+        torch.cuda.synchronize()
+        assert torch.equal(a[3], b[3]) and int(a[3][0]) >= 1
+        n = int(a[3][0])
+        for x, y in zip(a[:3], b[:3]):
+            assert x.shape == y.shape and torch.equal(x[0, :n], y[0, :n])
+        return a
+
+    def setboth(**kw):
+        for d in (seq, ref):
+            for k, v in kw.items():
+                setattr(d, k, v)
+
+    for s in range(4):
+        same(100 + s)
+    assert len(replays) == 2 and len(seq._tls.seqs) == 1                    # calls 3 and 4 were replays
+    old = next(iter(seq._tls.seqs.values()))
+    # (i) thresholds + cap_o between two calls of the same frame shape
+    setboth(thresholds=(0.6, 0.65, 0.72), cap_o=5)
+    a = same(110)
+    assert len(replays) == 2 and a[0].shape == (1, 5, 4)                    # not replayed: the old list went away ...
+    lst = next(iter(seq._tls.seqs.values()), None)
+    assert lst is not old
+    for s in range(3):
+        same(111 + s)
+    assert len(replays) >= 4 and next(iter(seq._tls.seqs.values()))["cfg"][3] == (0.6, 0.65, 0.72)   # ... a new one is in use
+    # (ii) the stand-alone crop kernel is outside SEQ_FN
+    n0 = len(replays)
+    setboth(fused_crop=False)
+    for s in range(5):
+        same(120 + s)
+    assert len(replays) == n0 and not seq._tls.seqs                          # nothing replayed, nothing kept
+    setboth(fused_crop=True)
+    for s in range(4):
+        same(130 + s)
+    assert len(replays) > n0 and len(seq._tls.seqs) == 1                     # back: recorded afresh (the old list was dropped)
+    # (iii) the recorder refuses a list when another entry point ran during the recording
+    lib = _lib.load()
+    lib.start_recording()
+    x = torch.randn(4, 512, device="cuda")
+    lib.fr_l2norm_rows_f32(_lib.ptr(x), _lib.ptr(x), 4, 512, _lib.stream_ptr())
+    assert lib.stop_recording() is None and lib.recording_invalid() == "fr_l2norm_rows_f32"
+    lib.start_recording()
+    assert lib.stop_recording() == [] and lib.recording_invalid() is None
+    # (iv) one_stream (profiling: every level on the caller's stream) is honoured, i.e. never replayed
+    n1 = len(replays)
+    setboth(one_stream=True)
+    for s in range(4):
+        same(140 + s)
+    assert len(replays) == n1
+
+
 @pytest.mark.parametrize("negative_slopes", [False, True])
 def test_pnet_conv1_kernel_vs_oracle_and_16x16x4_form(negative_slopes):
     """P-Net conv1 (+ pyramid resize, PReLU, 2x2 ceil pool) runs as its own 4x4x1-MFMA kernel (csrc/pnet_conv1.hip).

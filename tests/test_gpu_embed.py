@@ -368,6 +368,74 @@ def test_r50_variant_vs_oracle():
     assert abs(net.flops_per_face / 1e9 - 12.6) < 0.2          # 12.62 GFLOP / face
 
 
+def _cos_rows(a, b):
+    return (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+
+
+@pytest.mark.parametrize("B", [100, 128])
+def test_r100_mid_batch_modes_vs_oracle(r100, B):
+    """The two batch-size modes no oracle test reached (parity item 3): 100 faces (49 - 127: every conv layer by
+    layer on the halo / walk64 kernels) and exactly 128 (config C3's batch: the 14x14 stage kernel on, the 28x28 stage kernel
+    off, every walk64 face walk cut in two) against oracle.nets on eight of their faces spread over the batch - a face's
+    embedding does not depend on its batch mates, so eight rows pin the mode."""
+    from facerecognition_infrenceengine_amd import iresnet, weights
+    from oracle import nets as onets
+    assert iresnet.SMALL_BATCH < 100 < iresnet.STAGE14_MIN_BATCH == 128 < iresnet.STAGE28_MIN_BATCH and 128 not in iresnet.WALK64_SKIP
+    xs = _structured_crops(B, 700 + B)
+    pick = [0, 1, B // 3, B // 2, B // 2 + 1, B - 9, B - 2, B - 1]
+    calls = []
+    for name in ("fr_conv_stage14_f16", "fr_conv_stage28_f16", "fr_conv_walk64_f16"):
+        orig = r100.lib._calls[name]
+        r100.lib._calls[name] = (lambda *a, _o=orig, _n=name: (calls.append(_n), _o(*a))[1])
+    try:
+        emb, normed = r100.forward(nchw_to_nhwc8(xs))
+    finally:
+        for name in ("fr_conv_stage14_f16", "fr_conv_stage28_f16", "fr_conv_walk64_f16"):
+            r100.lib._calls[name] = r100.lib._calls[name].__defaults__[0]
+    assert calls.count("fr_conv_stage14_f16") == (1 if B == 128 else 0) and "fr_conv_stage28_f16" not in calls
+    assert calls.count("fr_conv_walk64_f16") == 6
+    ref = onets.iresnet_forward(weights.synth_iresnet_state("r100", seed=1234), xs[pick], weights.IRESNET_LAYERS["r100"]).numpy()
+    got = emb[pick].cpu().numpy()
+    c = _cos_rows(got, ref)
+    print(f"\nr100, {B} faces, 8 of them vs the fp32 oracle: 1-cos max {(1 - c).max():.3e}")
+    assert (1 - c).max() < 1e-3, c
+    np.testing.assert_allclose(np.linalg.norm(normed.cpu().numpy(), axis=1), 1.0, atol=1e-6)
+
+
+def test_r50_on_the_batch_paths_vs_oracle():
+    """The reference's real recogniser is an IResNet-50 (infrenceServer.py:412-416 -> w600k_r50.onnx).  At 150
+    faces it takes the fast paths with OTHER run lengths than r100: the 14x14 stage kernel over 13 blocks (r100: 29), the
+    28x28 stage kernel over 3 (r100: 12), walk64 with other neighbours.  Eight faces spread over the batch against oracle.nets,
+    and the whole batch against the layer-by-layer path."""
+    from facerecognition_infrenceengine_amd import weights
+    from facerecognition_infrenceengine_amd.iresnet import IResNetHIP
+    from oracle import nets as onets
+    st = weights.synth_iresnet_state("r50", seed=77)
+    net = IResNetHIP(st, "r50", "cuda:0")
+    assert net.stage14["n"] == 13 and net.stage28["n"] == 3
+    B = 150
+    xs = _structured_crops(B, 909)
+    calls = []
+    for name in ("fr_conv_stage14_f16", "fr_conv_stage28_f16", "fr_conv_walk64_f16"):
+        orig = net.lib._calls[name]
+        net.lib._calls[name] = (lambda *a, _o=orig, _n=name: (calls.append(_n), _o(*a))[1])
+    try:
+        emb, normed = net.forward(nchw_to_nhwc8(xs))
+    finally:
+        for name in ("fr_conv_stage14_f16", "fr_conv_stage28_f16", "fr_conv_walk64_f16"):
+            net.lib._calls[name] = net.lib._calls[name].__defaults__[0]
+    assert calls.count("fr_conv_stage14_f16") == 1 and calls.count("fr_conv_stage28_f16") == 1
+    pick = [0, 1, 49, 75, 76, 140, 148, 149]
+    ref = onets.iresnet_forward(st, xs[pick], weights.IRESNET_LAYERS["r50"]).numpy()
+    c = _cos_rows(emb[pick].cpu().numpy(), ref)
+    print(f"\nr50, 150 faces (stage-14 run of 13, stage-28 run of 3), 8 of them vs the fp32 oracle: 1-cos max {(1 - c).max():.3e}")
+    assert (1 - c).max() < 1e-3, c
+    net.use_stage14 = net.use_stage28 = net.use_walk64 = False
+    e_layer, _ = net.forward(nchw_to_nhwc8(xs))
+    assert float((1 - torch.nn.functional.cosine_similarity(emb, e_layer)).max()) < 2e-5
+    np.testing.assert_allclose(np.linalg.norm(normed.cpu().numpy(), axis=1), 1.0, atol=1e-6)
+
+
 # ---------------------------------------------------------------- the 14x14 stage as one launch (conv_stage14.hip)
 @pytest.mark.parametrize("B,nblocks", [(1, 1), (3, 2), (5, 3)])
 def test_stage14_kernel_vs_torch(lib, B, nblocks):

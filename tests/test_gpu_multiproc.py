@@ -44,6 +44,8 @@ def test_bench_gpus2_launches_itself_and_prints_rank0_line():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and "self_check" in d
+    # the N > 1 line explains itself: the exchange's four parts, bracketed by HIP events inside ShardedGalleryMatcher.match
+    assert set(d["exchange_ms"]) == {"gather_q", "scan", "gather_c", "reduce", "samples"} and d["exchange_ms"]["samples"] >= 3
 
 
 def test_bench_force_exchange_runs_both_all_gathers_over_rccl():
@@ -62,3 +64,5 @@ def test_bench_force_exchange_runs_both_all_gathers_over_rccl():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and "self_check" in d
     assert d["planted_top1"]["faces"] > 0 and d["planted_top1"]["matched_own_row"] > 0      # ids came through the exchange
+    ex = d["exchange_ms"]                                                                    # ... and its parts are timed
+    assert set(ex) == {"gather_q", "scan", "gather_c", "reduce", "samples"} and all(ex[k] > 0 for k in ("gather_q", "scan", "gather_c", "reduce"))

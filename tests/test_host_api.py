@@ -221,6 +221,7 @@ def test_camera_manager_backs_off_on_failed_reads_and_drains_results_by_default(
             self.reads += 1
             if self.source == "dead" or (self.source == "flaky" and self.generation == 1):
                 return False, None                              # a dropped stream: fails immediately, every time
+            time.sleep(0.001)                                   # a live camera blocks in read() (and yields the interpreter)
             return True, np.full((4, 6, 3), 5, np.uint8)
 
         def release(self):
@@ -240,7 +241,7 @@ def test_camera_manager_backs_off_on_failed_reads_and_drains_results_by_default(
     cm = CameraManager(None, processor=Proc(), capture_factory=lambda s: caps.append(FlakyCap(s)) or caps[-1],
                        reopen_after=3, dead_after=8)
     cm.start_cameras(["flaky", "dead", "good"], "acme")
-    deadline = time.time() + 10
+    deadline = time.time() + 30
     while time.time() < deadline and not (cm.stats["dead_sources"] and cm.latest_frame("flaky") is not None
                                           and cm.stats["frames"] > 30):
         time.sleep(0.01)
