@@ -34,6 +34,12 @@ struct RoArgs {
     const float* w;                            // [27][NG * 4] f32: k = (kh * 3 + kw) * 3 + channel (R, G, B)
     const float* bias; const float* slope;     // [NG * 4]
     float* y;                                  // [slots][P][P][COUT]
+    // SPLIT: the pooled map leaves as split f16 instead - [slots][P*P][hi 32 ch | lo 32 ch] (x = hi + lo, 128 B per pixel,
+    // channels >= COUT zero): what fr_ro_conv2_split streams into LDS
+    unsigned char* ys;
+    // LIST: the block's slots are positions of a compact list of slot numbers (the crops the exact pass re-evaluates):
+    // slot s -> box / frame of list[s], output row s; *list_count entries (clamped to list_cap)
+    const int32_t* list; const int32_t* list_count; int list_cap;
 };
 
 typedef unsigned long long u64_unaligned_r __attribute__((aligned(1)));
@@ -62,7 +68,7 @@ __device__ __forceinline__ float vmax_r(float x, float y) {        // no canonic
 // S: crop size; NG: cout quads (COUT = 4 NG real channels written); PB: pooled rows per band (a band = 2 PB + 1 conv rows);
 // RPB: consecutive crop slots per block.  The source bytes of the NEXT valid slot's crop are fetched (raw, into
 // registers) before the current slot's conv and blended into LDS after it, so the frame gather's latency is covered.
-template <int S, int NG, int COUT, int PB, int RPB>
+template <int S, int NG, int COUT, int PB, int RPB, bool SPLIT = false, bool LIST = false>
 __global__ __launch_bounds__(256) void crop_conv1_kernel(RoArgs a) {
     constexpr int C = S - 2;                                     // conv map size
     constexpr int P = (C - 3 + 1) / 2 + 1;                       // ceil((C - 3) / 2) + 1 pooled size (ceil mode)
@@ -78,18 +84,28 @@ __global__ __launch_bounds__(256) void crop_conv1_kernel(RoArgs a) {
     float* xin = lds_ro;                                         // [S*S][3]
     int4v* tab = reinterpret_cast<int4v*>(lds_ro + ((S * S * 3 + 3) & ~3));          // [2][2 S] lerp tables (double-buffered)
     float4* sbox_mem = reinterpret_cast<float4*>(tab + 4 * S);  // [RPB] the block's boxes (one global read, off the per-slot path)
-    float* ot = reinterpret_cast<float*>(sbox_mem + RPB);        // [BR * C][CS] conv tile
+    int* sorig = reinterpret_cast<int*>(sbox_mem + RPB);         // [RPB] the slots' numbers in the cascade's slot space (LIST: list[s])
+    float* ot = reinterpret_cast<float*>(sorig + ((RPB + 3) & ~3));      // [BR * C][CS] conv tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // a block's RPB consecutive slots lie in ONE frame (the host picks RPB | cap), and a frame's candidates are a prefix of
     // its slots: the block's valid slots are the interval [slot, s_end) - one read of the count, no search
     const int s_first = blockIdx.x * RPB;
-    const int fblk = s_first / a.cap;
-    const int s_end = min(s_first + RPB, fblk * a.cap + a.counts[fblk]);
+    int s_end;
+    if constexpr (LIST) {
+        s_end = min(s_first + RPB, min(*a.list_count, a.list_cap));
+    } else {
+        const int fblk = s_first / a.cap;
+        s_end = min(s_first + RPB, fblk * a.cap + a.counts[fblk]);
+    }
     int slot = s_first;
     if (slot >= s_end) return;                                   // only empty slots: no work, outputs unwritten
     auto next_valid = [&](int s) { return s < s_end ? s : -1; };
     float4* sbox = sbox_mem;
-    if (tid < s_end - s_first) sbox[tid] = *reinterpret_cast<const float4*>(a.boxes + (int64_t)(s_first + tid) * 4);
+    if (tid < s_end - s_first) {
+        const int o = LIST ? a.list[s_first + tid] : s_first + tid;
+        sorig[tid] = o;
+        sbox[tid] = *reinterpret_cast<const float4*>(a.boxes + (int64_t)o * 4);
+    }
     __syncthreads();
     // ---- weights: slot c = k * NG + g -> lanes 4 (c % 16) + r of register c / 16 hold W[k][4g + r]
     float wreg[NW];
@@ -128,7 +144,7 @@ __global__ __launch_bounds__(256) void crop_conv1_kernel(RoArgs a) {
         }
     };
     auto load_crop = [&](int sl, int buf) __attribute__((always_inline)) {
-        const int f = sl / a.cap;
+        const int f = sorig[sl - s_first] / a.cap;
         const uint8_t* fr = a.frames + (int64_t)f * a.H * a.W * 3;
         const int lim = f == a.nframes - 1 ? a.H * a.W * 3 - 8 : 0x7fffffff;
         bool special = false;
@@ -272,7 +288,28 @@ __global__ __launch_bounds__(256) void crop_conv1_kernel(RoArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) m[k] = m[k] > 0.f ? m[k] : m[k] * sv[k];
             }
-            *reinterpret_cast<float4v*>(yo + ((int64_t)(p0 + pyl) * P + px) * COUT + qd * 4) = m;
+            if constexpr (SPLIT) {
+                half4 hi, lo;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const half_t h = (half_t)m[k];
+                    hi[k] = h; lo[k] = (half_t)(m[k] - (float)h);
+                }
+                unsigned char* o2 = a.ys + ((int64_t)slot * P * P + (p0 + pyl) * P + px) * 128 + qd * 8;
+                *reinterpret_cast<half4*>(o2) = hi;
+                *reinterpret_cast<half4*>(o2 + 64) = lo;
+                if constexpr (COUT < 32) {                                   // the K padding (channels COUT .. 31) is zero
+                    if (qd == Q4 - 1) {
+#pragma unroll
+                        for (int z = COUT / 4; z < 8; ++z) {
+                            *reinterpret_cast<half4*>(o2 + (z - qd) * 8) = half4{0, 0, 0, 0};
+                            *reinterpret_cast<half4*>(o2 + 64 + (z - qd) * 8) = half4{0, 0, 0, 0};
+                        }
+                    }
+                }
+            } else {
+                *reinterpret_cast<float4v*>(yo + ((int64_t)(p0 + pyl) * P + px) * COUT + qd * 4) = m;
+            }
         }
         if (band + 1 < NBAND) __syncthreads();                               // the next band overwrites the conv tile
     }
@@ -281,13 +318,13 @@ __global__ __launch_bounds__(256) void crop_conv1_kernel(RoArgs a) {
     }
 }
 
-template <int S, int NG, int COUT, int PB, int RPB>
+template <int S, int NG, int COUT, int PB, int RPB, bool SPLIT = false, bool LIST = false>
 int launch_ro(const RoArgs& a, int nslots, hipStream_t s) {
     constexpr int C = S - 2;
     constexpr int rows = 2 * PB + 1 < C ? 2 * PB + 1 : C;
     constexpr int CS = (NG * 4) % 32 ? NG * 4 : NG * 4 + 4;
-    const size_t lds = (size_t)(((S * S * 3 + 3) & ~3) + 4 * S * 4 + RPB * 4 + rows * C * CS) * sizeof(float);
-    auto kern = crop_conv1_kernel<S, NG, COUT, PB, RPB>;
+    const size_t lds = (size_t)(((S * S * 3 + 3) & ~3) + 4 * S * 4 + RPB * 4 + ((RPB + 3) & ~3) + rows * C * CS) * sizeof(float);
+    auto kern = crop_conv1_kernel<S, NG, COUT, PB, RPB, SPLIT, LIST>;
     if (lds > 64 * 1024) {
         static FrDevLatch latch;
         if (!fr_raise_lds(reinterpret_cast<const void*>(kern), lds, latch)) {
@@ -308,7 +345,7 @@ extern "C" int fr_crop_conv1_f32(int net, const uint8_t* frames, int nframes, in
     FR_REQUIRE(nframes > 0 && cap > 0 && H > 0 && W > 0 && (int64_t)H * W * 3 < (1ll << 31) && (int64_t)H * W * 3 >= 8,
                "fr_crop_conv1_f32: bad frame size");
     FR_REQUIRE((int64_t)nframes * cap < (1ll << 31), "fr_crop_conv1_f32: too many slots");
-    RoArgs a{frames, nframes, H, W, boxes, counts, cap, w, bias, slope, y};
+    RoArgs a{frames, nframes, H, W, boxes, counts, cap, w, bias, slope, y, nullptr, nullptr, nullptr, 0};
     int rc;
     // bands of 4 / 2 pooled rows keep the conv tile at 22 / 33 KB (5 / 2 blocks per CU); 8 / 4 slots per block (measured:
     // one band 785 / 626 us, these bands with one slot per block 569 / 369, as below 508 / 356 us per 64-frame batch)
@@ -320,5 +357,45 @@ extern "C" int fr_crop_conv1_f32(int net, const uint8_t* frames, int nframes, in
     else { FR_REQUIRE(false, "fr_crop_conv1_f32: net must be 0 (R-Net) or 1 (O-Net)"); }
     if (rc != FR_OK) return rc;
     FR_CHECK_LAUNCH("crop_conv1_kernel");
+    return FR_OK;
+}
+
+// The same layer with the pooled map written as SPLIT f16 (x = hi + lo; [slots][P*P][hi 32 ch | lo 32 ch], 128 B per pixel):
+// the input format of fr_ro_conv2_split.  Same arithmetic up to the split, which is exact to 22 mantissa bits.
+extern "C" int fr_crop_conv1_split(int net, const uint8_t* frames, int nframes, int H, int W, const float* boxes,
+                                   const int32_t* counts, int cap, const float* w, const float* bias, const float* slope,
+                                   void* y_split, fr_stream_t stream) {
+    FR_REQUIRE(frames && boxes && counts && w && bias && slope && y_split, "fr_crop_conv1_split: null pointer");
+    FR_REQUIRE(nframes > 0 && cap > 0 && H > 0 && W > 0 && (int64_t)H * W * 3 < (1ll << 31) && (int64_t)H * W * 3 >= 8,
+               "fr_crop_conv1_split: bad frame size");
+    FR_REQUIRE((int64_t)nframes * cap < (1ll << 31), "fr_crop_conv1_split: too many slots");
+    RoArgs a{frames, nframes, H, W, boxes, counts, cap, w, bias, slope, nullptr, (unsigned char*)y_split, nullptr, nullptr, 0};
+    hipStream_t s = fr_stream(stream);
+    const int64_t nslots = (int64_t)nframes * cap;
+    int rc;
+    if (net == 0) rc = cap % 8 == 0 && nslots >= 8192 ? launch_ro<24, 7, 28, 4, 8, true>(a, nframes * cap, s) : launch_ro<24, 7, 28, 4, 1, true>(a, nframes * cap, s);
+    else if (net == 1) rc = cap % 4 == 0 && nslots >= 2048 ? launch_ro<48, 8, 32, 2, 4, true>(a, nframes * cap, s) : launch_ro<48, 8, 32, 2, 1, true>(a, nframes * cap, s);
+    else { FR_REQUIRE(false, "fr_crop_conv1_split: net must be 0 (R-Net) or 1 (O-Net)"); }
+    if (rc != FR_OK) return rc;
+    FR_CHECK_LAUNCH("crop_conv1_kernel (split)");
+    return FR_OK;
+}
+
+// The f32 layer for a compact LIST of slots (the exact pass over the crops whose approximate logit lies within the margin of
+// the threshold, fr_ro_margin_list): row i of `y` is the pooled conv1 map of slot list[i], i < min(*list_count, list_cap).
+extern "C" int fr_crop_conv1_list_f32(int net, const uint8_t* frames, int nframes, int H, int W, const float* boxes, int cap,
+                                      const int32_t* list, const int32_t* list_count, int list_cap, const float* w,
+                                      const float* bias, const float* slope, float* y, fr_stream_t stream) {
+    FR_REQUIRE(frames && boxes && list && list_count && w && bias && slope && y, "fr_crop_conv1_list_f32: null pointer");
+    FR_REQUIRE(nframes > 0 && cap > 0 && list_cap > 0 && H > 0 && W > 0 && (int64_t)H * W * 3 < (1ll << 31) && (int64_t)H * W * 3 >= 8,
+               "fr_crop_conv1_list_f32: bad argument");
+    RoArgs a{frames, nframes, H, W, boxes, nullptr, cap, w, bias, slope, y, nullptr, list, list_count, list_cap};
+    hipStream_t s = fr_stream(stream);
+    int rc;
+    if (net == 0) rc = launch_ro<24, 7, 28, 4, 1, false, true>(a, list_cap, s);
+    else if (net == 1) rc = launch_ro<48, 8, 32, 2, 1, false, true>(a, list_cap, s);
+    else { FR_REQUIRE(false, "fr_crop_conv1_list_f32: net must be 0 (R-Net) or 1 (O-Net)"); }
+    if (rc != FR_OK) return rc;
+    FR_CHECK_LAUNCH("crop_conv1_kernel (list)");
     return FR_OK;
 }

@@ -383,15 +383,14 @@ def test_r100_mid_batch_modes_vs_oracle(r100, B):
     assert iresnet.SMALL_BATCH < 100 < iresnet.STAGE14_MIN_BATCH == 128 < iresnet.STAGE28_MIN_BATCH and 128 not in iresnet.WALK64_SKIP
     xs = _structured_crops(B, 700 + B)
     pick = [0, 1, B // 3, B // 2, B // 2 + 1, B - 9, B - 2, B - 1]
-    calls = []
+    calls, saved = [], {}
     for name in ("fr_conv_stage14_f16", "fr_conv_stage28_f16", "fr_conv_walk64_f16"):
-        orig = r100.lib._calls[name]
-        r100.lib._calls[name] = (lambda *a, _o=orig, _n=name: (calls.append(_n), _o(*a))[1])
+        saved[name] = r100.lib._calls[name]
+        r100.lib._calls[name] = (lambda *a, _o=saved[name], _n=name: (calls.append(_n), _o(*a))[1])
     try:
         emb, normed = r100.forward(nchw_to_nhwc8(xs))
     finally:
-        for name in ("fr_conv_stage14_f16", "fr_conv_stage28_f16", "fr_conv_walk64_f16"):
-            r100.lib._calls[name] = r100.lib._calls[name].__defaults__[0]
+        r100.lib._calls.update(saved)
     assert calls.count("fr_conv_stage14_f16") == (1 if B == 128 else 0) and "fr_conv_stage28_f16" not in calls
     assert calls.count("fr_conv_walk64_f16") == 6
     ref = onets.iresnet_forward(weights.synth_iresnet_state("r100", seed=1234), xs[pick], weights.IRESNET_LAYERS["r100"]).numpy()
@@ -415,15 +414,14 @@ def test_r50_on_the_batch_paths_vs_oracle():
     assert net.stage14["n"] == 13 and net.stage28["n"] == 3
     B = 150
     xs = _structured_crops(B, 909)
-    calls = []
+    calls, saved = [], {}
     for name in ("fr_conv_stage14_f16", "fr_conv_stage28_f16", "fr_conv_walk64_f16"):
-        orig = net.lib._calls[name]
-        net.lib._calls[name] = (lambda *a, _o=orig, _n=name: (calls.append(_n), _o(*a))[1])
+        saved[name] = net.lib._calls[name]
+        net.lib._calls[name] = (lambda *a, _o=saved[name], _n=name: (calls.append(_n), _o(*a))[1])
     try:
         emb, normed = net.forward(nchw_to_nhwc8(xs))
     finally:
-        for name in ("fr_conv_stage14_f16", "fr_conv_stage28_f16", "fr_conv_walk64_f16"):
-            net.lib._calls[name] = net.lib._calls[name].__defaults__[0]
+        net.lib._calls.update(saved)
     assert calls.count("fr_conv_stage14_f16") == 1 and calls.count("fr_conv_stage28_f16") == 1
     pick = [0, 1, 49, 75, 76, 140, 148, 149]
     ref = onets.iresnet_forward(st, xs[pick], weights.IRESNET_LAYERS["r50"]).numpy()
