@@ -107,6 +107,11 @@ SIGNATURES = {
     "fr_dconv_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "fr_dconv_mfma_f32": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P]),
     "fr_crop_conv1_f32": (_I, [_I, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "fr_crop_conv1_split": (_I, [_I, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "fr_crop_conv1_list_f32": (_I, [_I, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "fr_ro_conv2_split": (_I, [_I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
+    "fr_ro_margin_list": (_I, [_P, _I, _P, _I, _I, _F, _F, _P, _P, _I, _P]),
+    "fr_ro_scatter_rows": (_I, [_P, _P, _P, _I, _I, _P, _P]),
     "fr_pnet23_workspace_bytes": (_Z, [_I, _I, _I]),
     "fr_pnet23_split_f16": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _Z, _P]),
     "fr_maxpool_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -165,6 +165,19 @@ class MTCNNHIP:
             r["conv1.weight"].permute(2, 3, 1, 0).reshape(27, 28), r["conv1.bias"], r["prelu1.weight"]))
         self._oc1 = tuple(t.to(torch.float32).contiguous().to(d) for t in (
             o["conv1.weight"].permute(2, 3, 1, 0).reshape(27, 32), o["conv1.bias"], o["prelu1.weight"]))
+        # second R-/O-Net layer on the f16 matrix cores with split-precision operands (csrc/ro_conv2.hip; batches of >= 8 frames):
+        # weights as [cout][tap][32 channels] f32; the crops whose logit lies within ``ro_margin`` of the stage threshold are
+        # re-evaluated by the all-f32 layers, so every keep / reject decision is that of f32 arithmetic
+        self.split_ro = True
+        self.ro_margin = 1e-3               # in logit units; the split path's measured head error is ~1e-6
+        self.ro_list_cap = (1024, 256)      # slots of the exact pass's work list (R-Net, O-Net); entries past it keep the split values
+        def c2w(w):
+            o, c = w.shape[0], w.shape[1]
+            wp = torch.zeros((o, 9, 32))
+            wp[:, :, :c] = w.permute(0, 2, 3, 1).reshape(o, 9, c)
+            return wp
+        self._rc2 = tuple(t.to(torch.float32).contiguous().to(d) for t in (c2w(r["conv2.weight"]), r["conv2.bias"], r["prelu2.weight"]))
+        self._oc2 = tuple(t.to(torch.float32).contiguous().to(d) for t in (c2w(o["conv2.weight"]), o["conv2.bias"], o["prelu2.weight"]))
         self.r1 = _MConv(10, r["conv1.weight"], r["conv1.bias"], r["prelu1.weight"], d)
         self.r2 = _MConv(11, r["conv2.weight"], r["conv2.bias"], r["prelu2.weight"], d)
         self.r3 = _MConv(12, r["conv3.weight"], r["conv3.bias"], r["prelu3.weight"], d)
@@ -293,27 +306,68 @@ class MTCNNHIP:
                                    _lib.ptr(b), _lib.ptr(s), _lib.ptr(y), self._s)
         return y
 
-    def rnet(self, x, B, counts=None, cap=0, x1=None):
+    def crop_conv12_split(self, net, frames, boxes, counts, cap):
+        """crop -> conv1 -> pool (map written as split f16) -> conv2 -> pool on the f16 matrix cores: the net's pooled conv2
+        map of every valid slot, f32 [N*cap, 4, 4, 48] / [N*cap, 10, 10, 64]."""
+        N, H, W, _ = frames.shape
+        w1, b1, s1 = self._rc1 if net == 0 else self._oc1
+        w2, b2, s2 = self._rc2 if net == 0 else self._oc2
+        p1, p2, c2 = (11, 4, 48) if net == 0 else (23, 10, 64)
+        xs = self._new((N * cap, p1 * p1, 128), torch.uint8)
+        self.lib.fr_crop_conv1_split(net, self._fptr(frames), N, H, W, _lib.ptr(boxes), _lib.ptr(counts), cap, _lib.ptr(w1),
+                                     _lib.ptr(b1), _lib.ptr(s1), _lib.ptr(xs), self._s)
+        y = self._f32(N * cap, p2, p2, c2)
+        lc = self._i32(1)                   # the exact pass's list counter: cleared by the conv2 kernel, filled by fr_ro_margin_list
+        self.lib.fr_ro_conv2_split(net, _lib.ptr(xs), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(s2), _lib.ptr(y), N * cap,
+                                   _lib.ptr(counts), cap, _lib.ptr(lc), self._s)
+        return y, lc
+
+    def exact_pass(self, net, frames, boxes, counts, cap, head, thr, lc):
+        """The split-precision heads ``head`` [N*cap, 6 | 16] of the crops whose logit difference lies within ``ro_margin`` of
+        the stage threshold are replaced by those of the all-f32 layers (compact work list, device-side count: no sync)."""
+        N, H, W, _ = frames.shape
+        w1, b1, s1 = self._rc1 if net == 0 else self._oc1
+        lcap = self.ro_list_cap[net]
+        nh = head.shape[1]
+        lst = self._i32(lcap)
+        self.lib.fr_ro_margin_list(_lib.ptr(head), nh, _lib.ptr(counts), N, cap, math.log(thr / (1.0 - thr)), self.ro_margin,
+                                   _lib.ptr(lst), _lib.ptr(lc), lcap, self._s)
+        p, c = (11, 28) if net == 0 else (23, 32)
+        x1 = self._f32(lcap, p, p, c)
+        self.lib.fr_crop_conv1_list_f32(net, self._fptr(frames), N, H, W, _lib.ptr(boxes), cap, _lib.ptr(lst), _lib.ptr(lc), lcap,
+                                        _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(s1), _lib.ptr(x1), self._s)
+        exact = (self.rnet if net == 0 else self.onet)(None, lcap, lc, lcap, x1=x1)
+        self.lib.fr_ro_scatter_rows(_lib.ptr(exact), _lib.ptr(lst), _lib.ptr(lc), lcap, nh, _lib.ptr(head), self._s)
+        self._ro_lists = getattr(self, "_ro_lists", {})
+        self._ro_lists[net] = lc            # diagnostics / tests: how many crops the exact pass took
+
+    def rnet(self, x, B, counts=None, cap=0, x1=None, x2=None):
         """counts / cap: only the first counts[frame] of a frame's cap crop slots are computed (device-side).
-        x1: conv1's pooled map when it was computed straight from the frames (crop_conv1)."""
+        x1: conv1's pooled map when it was computed straight from the frames (crop_conv1); x2: conv2's (crop_conv12_split)."""
         k = dict(counts=counts, cap=cap)
-        if x1 is not None:
+        if x2 is not None:
+            x, h, w = x2, 4, 4
+        elif x1 is not None:
             x, h, w = x1, 11, 11
         else:
             x, h, w = self._dconv(x, self.r1, B, 24, 24, **k)   # + fused 3x3/s2 pool -> 11x11
-        x, h, w = self._dconv(x, self.r2, B, h, w, **k)     # + fused 3x3/s2 pool -> 4x4
+        if x2 is None:
+            x, h, w = self._dconv(x, self.r2, B, h, w, **k)     # + fused 3x3/s2 pool -> 4x4
         x, h, w = self._dconv(x, self.r3, B, h, w, **k)
         x, h, w = self._dconv(x, self.r4, B, h, w, **k)
         x, h, w = self._dconv(x, self.r5, B, 1, 1, **k)
         return x.reshape(B, 6)
 
-    def onet(self, x, B, counts=None, cap=0, x1=None):
+    def onet(self, x, B, counts=None, cap=0, x1=None, x2=None):
         k = dict(counts=counts, cap=cap)
-        if x1 is not None:
+        if x2 is not None:
+            x, h, w = x2, 10, 10
+        elif x1 is not None:
             x, h, w = x1, 23, 23
         else:
             x, h, w = self._dconv(x, self.o1, B, 48, 48, **k)   # + fused 3x3/s2 pool -> 23x23
-        x, h, w = self._dconv(x, self.o2, B, h, w, **k)     # + fused 3x3/s2 pool -> 10x10
+        if x2 is None:
+            x, h, w = self._dconv(x, self.o2, B, h, w, **k)     # + fused 3x3/s2 pool -> 10x10
         x, h, w = self._dconv(x, self.o3, B, h, w, **k)     # + fused 2x2/s2 pool -> 4x4
         x, h, w = self._dconv(x, self.o4, B, h, w, **k)
         x, h, w = self._dconv(x, self.o5, B, h, w, **k)
@@ -474,7 +528,12 @@ class MTCNNHIP:
             # ---- stage 2
             B2 = N * self.cap_p
             crops = None
-            if self.fused_crop and trace is None:       # crop + conv1 + pool in one kernel: no crop tensor in HBM
+            split = self.split_ro and self.fused_crop and trace is None and N >= 8
+            if split:                                   # conv2 on the f16 matrix cores (split precision) + exact pass at the threshold
+                y2, lc2 = self.crop_conv12_split(0, frames, b1, c1, self.cap_p)
+                head2 = self.rnet(None, B2, c1, self.cap_p, x2=y2)
+                self.exact_pass(0, frames, b1, c1, self.cap_p, head2, t1, lc2)
+            elif self.fused_crop and trace is None:     # crop + conv1 + pool in one kernel: no crop tensor in HBM
                 head2 = self.rnet(None, B2, c1, self.cap_p, x1=self.crop_conv1(0, frames, b1, c1, self.cap_p))
             else:
                 crops = self._f32(B2, 24, 24, 4)
@@ -493,7 +552,11 @@ class MTCNNHIP:
                              stage2_counts=c2)
             # ---- stage 3
             B3 = N * self.cap_r
-            if self.fused_crop and trace is None:
+            if split:
+                y3, lc3 = self.crop_conv12_split(1, frames, b2, c2, self.cap_r)
+                head3 = self.onet(None, B3, c2, self.cap_r, x2=y3)
+                self.exact_pass(1, frames, b2, c2, self.cap_r, head3, t2, lc3)
+            elif self.fused_crop and trace is None:
                 head3 = self.onet(None, B3, c2, self.cap_r, x1=self.crop_conv1(1, frames, b2, c2, self.cap_r))
             else:
                 crops3 = self._f32(B3, 48, 48, 4)

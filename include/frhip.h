@@ -327,6 +327,35 @@ int fr_dconv_mfma_f32(int layer, const float* x, const float* w, const float* bi
 int fr_crop_conv1_f32(int net, const uint8_t* frames, int nframes, int H, int W, const float* boxes,
                       const int32_t* counts, int cap, const float* w, const float* bias, const float* slope,
                       float* y, fr_stream_t stream);
+/* The same layer with its pooled map written as SPLIT f16 (x = hi + lo, hi = f16(x), lo = f16(x - hi)):
+ * y_split [nframes*cap][P*P pixels][hi 32 channels | lo 32 channels], 128 B per pixel, channels >= Cout zero (P = 11 / 23) -
+ * the operand format of fr_ro_conv2_split.  Same slots computed / left unwritten as fr_crop_conv1_f32. */
+int fr_crop_conv1_split(int net, const uint8_t* frames, int nframes, int H, int W, const float* boxes,
+                        const int32_t* counts, int cap, const float* w, const float* bias, const float* slope,
+                        void* y_split, fr_stream_t stream);
+/* fr_crop_conv1_f32 for a compact LIST of slots: row i of y is the f32 map of slot list[i], i < min(*list_count, list_cap)
+ * (device-side count; boxes / frames are indexed by list[i], frame = list[i] / cap). */
+int fr_crop_conv1_list_f32(int net, const uint8_t* frames, int nframes, int H, int W, const float* boxes, int cap,
+                           const int32_t* list, const int32_t* list_count, int list_cap, const float* w,
+                           const float* bias, const float* slope, float* y, fr_stream_t stream);
+/* R-Net / O-Net SECOND layer on the f16 matrix cores with split-precision operands (three v_mfma_f32_16x16x32_f16 per
+ * product term, f32 accumulate; heads differ from the f32 layers by ~1e-6): net 0: [.,11,11,28] -> conv 3x3 -> PReLU ->
+ * 3x3/s2 pool -> y f32 [nslots,4,4,48]; net 1: [.,23,23,32] -> ... -> [nslots,10,10,64] - the outputs of layers 11 / 21 of
+ * fr_dconv_mfma_f32.  x_split: fr_crop_conv1_split's map; w f32 [Cout][9 taps][32 channels] (channels >= Cin zero);
+ * counts / cap as fr_dconv_mfma_f32 (nslots = frames x cap).  The cascade's keep / reject decisions stay those of f32
+ * arithmetic through the exact pass below.  zero_word (optional): a device int32 the kernel clears - the list counter of
+ * the fr_ro_margin_list call that follows in the stream (saves a memset launch). */
+int fr_ro_conv2_split(int net, const void* x_split, const float* w, const float* bias, const float* slope, float* y,
+                      int nslots, const int32_t* counts, int cap, int32_t* zero_word, fr_stream_t stream);
+/* The exact pass's work list: the valid slots whose logit difference head[s][1] - head[s][0] lies within `margin` of
+ * logit_thr = ln(t / (1 - t)) (t: the stage's probability threshold) are appended to list (any order); *list_count = how
+ * many there are (may exceed list_cap: entries past it are dropped, consumers clamp).  head f32 [nframes*cap][nhead].
+ * *list_count must be 0 on entry (fr_ro_conv2_split's zero_word, or the caller's memset). */
+int fr_ro_margin_list(const float* head, int nhead, const int32_t* counts, int nframes, int cap, float logit_thr,
+                      float margin, int32_t* list, int32_t* list_count, int list_cap, fr_stream_t stream);
+/* dst[list[i]][:] = src[i][:] for i < min(*list_count, list_cap): the exactly re-evaluated head rows go back to their slots. */
+int fr_ro_scatter_rows(const float* src, const int32_t* list, const int32_t* list_count, int list_cap, int ncols,
+                       float* dst, fr_stream_t stream);
 /* P-Net conv2 -> PReLU -> conv3 -> PReLU -> heads fused, on the f16 matrix cores with split-precision operands
  * (x = hi + lo in f16, three MFMAs per product term, f32 accumulate; ~1e-5 logit error), followed by an EXACT f32
  * re-evaluation of every cell whose logit1 - logit0 >= refine_logit_thr (pass ln(t/(1-t)) - 2e-3 for threshold t):

@@ -480,3 +480,93 @@ def test_crop_conv1_equals_crop_then_layer(negative_slopes):
         torch.cuda.synchronize()
         assert got.shape == want.shape == (N * cap, ho, wo, c)
         assert torch.equal(got[valid].view(torch.int32), want[valid].view(torch.int32)), net
+
+
+@pytest.mark.parametrize("negative_slopes", [False, True])
+def test_split_f16_conv2_layers_vs_f32_layers(negative_slopes):
+    """R-/O-Net's second layer on the f16 matrix cores with split-precision operands (csrc/ro_conv2.hip) against the f32
+    layers it replaces (fr_crop_conv1_f32 -> layer 11 / 21 of fr_dconv_mfma_f32), from the same frames and boxes: the
+    split conv1 map is hi + lo of the f32 map to 2^-21 relative (hi / lo layout and the zero K padding checked directly), the
+    pooled conv2 maps agree to ~1e-6 of the map's scale on every valid slot - boxes sticking out of every side, odd slot
+    counts (the R-Net kernel takes crops in pairs), an empty frame, negative PReLU slopes (no pooling before the activation)."""
+    from facerecognition_infrenceengine_amd import _lib, weights
+    from facerecognition_infrenceengine_amd.mtcnn import MTCNNHIP
+    st = weights.synth_mtcnn_states(seed=78)
+    if negative_slopes:
+        st[1]["prelu2.weight"] = st[1]["prelu2.weight"] * torch.where(torch.arange(48) % 3 == 0, -1.0, 1.0)
+        st[2]["prelu2.weight"] = st[2]["prelu2.weight"] * torch.where(torch.arange(64) % 5 == 0, -0.5, 1.0)
+    d = MTCNNHIP(*st, device="cuda:0")
+    lib = d.lib
+    N, H, W, cap = 4, 97, 131, 24
+    g = torch.Generator(device="cuda").manual_seed(12)
+    frames = torch.randint(0, 256, (N, H, W, 3), generator=g, device="cuda", dtype=torch.uint8)
+    x1 = torch.rand((N, cap), generator=g, device="cuda") * (W + 40) - 30
+    y1 = torch.rand((N, cap), generator=g, device="cuda") * (H + 40) - 30
+    sz = torch.rand((N, cap), generator=g, device="cuda") * 70 + 1
+    boxes = torch.stack([x1, y1, x1 + sz, y1 + sz * 1.2], -1).contiguous()
+    counts = torch.tensor([cap, 17, 0, 5], dtype=torch.int32, device="cuda")
+    valid = (torch.arange(cap, device="cuda")[None, :] < counts[:, None]).reshape(-1)
+    d._s = _lib.stream_ptr()
+    for net, layer2, p1, c1, shape2 in ((0, d.r2, 11, 28, (4, 4, 48)), (1, d.o2, 23, 32, (10, 10, 64))):
+        m1 = d.crop_conv1(net, frames, boxes, counts, cap)                           # f32 [N*cap, p1, p1, c1]
+        want, _, _ = d._dconv(m1, layer2, N * cap, p1, p1, counts=counts, cap=cap)
+        w1, b1, s1 = d._rc1 if net == 0 else d._oc1
+        xs = torch.full((N * cap, p1 * p1, 128), 0x7f, dtype=torch.uint8, device="cuda")
+        lib.fr_crop_conv1_split(net, _lib.ptr(frames), N, H, W, _lib.ptr(boxes), _lib.ptr(counts), cap, _lib.ptr(w1), _lib.ptr(b1),
+                                _lib.ptr(s1), _lib.ptr(xs), _lib.stream_ptr())
+        got, _ = d.crop_conv12_split(net, frames, boxes, counts, cap)
+        torch.cuda.synchronize()
+        hl = xs.view(torch.float16).reshape(N * cap, p1, p1, 2, 32).float()
+        hi, lo = hl[..., 0, :], hl[..., 1, :]
+        assert torch.equal(hi[valid][..., :c1], m1[valid].half().float())             # hi = f16(x)
+        assert float((hi[valid][..., :c1] + lo[valid][..., :c1] - m1[valid]).abs().max()) <= 2.0 ** -21 * float(m1[valid].abs().max())
+        assert float(hl[valid][..., c1:].abs().max() if c1 < 32 else 0.0) == 0.0      # the K padding is zero
+        assert got.shape == want.shape == (N * cap, *shape2)
+        err = float((got[valid] - want[valid]).abs().max())
+        scale = float(want[valid].abs().max())
+        print(f"\nnet {net}: split-f16 conv2 vs f32 conv2: max |d| {err:.3e} at scale {scale:.3f}")
+        assert err <= 4e-6 * scale, (net, err, scale)
+
+
+def test_split_ro_cascade_vs_f32_cascade_and_exact_pass():
+    """The cascade with the split-precision second layers (MTCNNHIP.split_ro, batches of >= 8 frames) against the all-f32
+    cascade on eight frames: (i) default margin: the same faces in the same order, scores within 5e-6, boxes / landmarks
+    within 1e-3 px (the split heads are ~1e-6 from the f32 ones; crops near the threshold are re-evaluated exactly, so the
+    keep / reject decisions are the f32 ones); (ii) with the margin opened wide every valid crop goes through the exact
+    pass (work lists sized to hold them all): the whole cascade is then BIT-identical to the f32 one - the list, the
+    compact f32 layers and the scatter put every head row back in its slot; (iii) the exact pass's list is small at the
+    default margin."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import synth_frame
+    from facerecognition_infrenceengine_amd import weights
+    from facerecognition_infrenceengine_amd.mtcnn import MTCNNHIP
+    st = weights.synth_mtcnn_states()
+    split = MTCNNHIP(*st, device="cuda:0")
+    ref = MTCNNHIP(*st, device="cuda:0")
+    ref.split_ro = False
+    frs = np.ascontiguousarray(np.stack([synth_frame(360, 640, 40 + i) for i in range(8)]))
+    frs[5] = 0                                                        # a frame with no candidate
+    x = torch.from_numpy(frs).cuda()
+    want = ref.detect_batch(x)
+    got = split.detect_batch(x)
+    torch.cuda.synchronize()
+    assert torch.equal(got[3], want[3]) and int(want[3].sum()) >= 8 and int(want[3][5]) == 0
+    listed = [int(split._ro_lists[k][0]) for k in (0, 1)]
+    valid2 = 8 * 512
+    print(f"\nsplit R-/O-Net: exact pass took {listed} crops (R-Net, O-Net) at margin {split.ro_margin}")
+    assert listed[0] < valid2 // 20 and listed[1] < 64
+    for f in range(8):
+        n = int(want[3][f])
+        assert float((got[1][f, :n] - want[1][f, :n]).abs().max() if n else 0.0) <= 5e-6
+        assert float((got[0][f, :n] - want[0][f, :n]).abs().max() if n else 0.0) <= 1e-3
+        assert float((got[2][f, :n] - want[2][f, :n]).abs().max() if n else 0.0) <= 1e-3
+    split.ro_margin = 1e9
+    split.ro_list_cap = (8 * 512, 8 * 64)
+    exact = split.detect_batch(x)
+    torch.cuda.synchronize()
+    assert torch.equal(exact[3], want[3])
+    for f in range(8):
+        n = int(want[3][f])
+        for a, b in zip(exact[:3], want[:3]):
+            assert torch.equal(a[f, :n], b[f, :n])
