@@ -205,6 +205,9 @@ def main():
     ap.add_argument("--ingest", default="resident", choices=["resident", "pinned"],
                     help="resident: frames already in HBM (the headline metric); pinned: every step's frames cross "
                          "PCIe from a pinned host ring on a copy stream (reported in DESIGN.md, never the headline)")
+    ap.add_argument("--ingest-chunks", type=int, default=1, help="A/B (pinned ingest): frame groups a step's upload is cut into")
+    ap.add_argument("--ingest-streams", type=int, default=1, help="A/B (pinned ingest): copy streams the groups are dealt over")
+    ap.add_argument("--ingest-ahead", type=int, default=0, help="A/B (pinned ingest): a step's upload is issued this many steps before the step itself is enqueued")
     ap.add_argument("--gallery-rows", type=int, default=0, help="override the gallery size (C4: 1 000 000 rows in total)")
     ap.add_argument("--gallery", default="f32", choices=["f32", "f16", "f8"],
                     help="f16 / f8: one-pass coarse scan of a 16- / 8-bit copy on the f16 / fp8 matrix cores + exact f32 "
@@ -311,7 +314,7 @@ def main():
     ingest = None
     if args.ingest == "pinned":
         from facerecognition_infrenceengine_amd.ingest import FrameIngest
-        ingest = FrameIngest(FRAMES, H, W, device, depth=args.depth + 1)
+        ingest = FrameIngest(FRAMES, H, W, device, depth=args.depth + 1 + args.ingest_ahead, chunks=args.ingest_chunks, streams=args.ingest_streams)
         for k in range(ingest.depth):       # what the capture side would have written
             ingest.host_buffer(k)[...] = batches[k % nbatch].cpu().numpy()
 
@@ -339,6 +342,7 @@ def main():
         """warmup untimed steps, then `steps` timed steps bracketed by barrier + synchronize on both sides.
         Returns (seconds, faces, batch latencies ms, per-step (idx, dec, counts) host copies)."""
         batch_ms, results = [], []
+        uploads = {}
 
         def enqueue(i):
             """One step, enqueued without any host synchronisation: fixed per-frame face slots, device-side counts,
@@ -348,7 +352,10 @@ def main():
             s_det, s_emb = pipes[i % len(pipes)]
             with torch.cuda.stream(s_emb):
                 if ingest is not None:          # PCIe-inclusive variant: pinned host ring -> device on a copy stream
-                    frames, ready = ingest.upload(i)
+                    for j in range(i, i + 1 + args.ingest_ahead):
+                        if j not in uploads:
+                            uploads[j] = ingest.upload(j)
+                    frames, ready = uploads.pop(i)
                     r = app.detect_embed_slots(frames, det_stream=s_det, ready_event=ready)
                     ingest.release(i)           # the warp (last reader of the frames) is queued on this stream by now
                 else:

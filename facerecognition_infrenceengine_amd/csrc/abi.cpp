@@ -30,7 +30,7 @@ inline float sf(const fr_call& c, int i) { union { uint32_t b; float f; } u; u.b
 extern "C" int fr_detect_sequence(const fr_call* calls, int ncalls) {
     FR_REQUIRE(calls && ncalls > 0, "fr_detect_sequence: no calls");
     // arity of every entry first: nothing is launched from a list that holds a short or malformed call
-    static const int arity[10] = {-1, 18, 20, 16, 18, 8, 13, 14, 2, 2};
+    static const int arity[10] = {-1, 18, 21, 16, 18, 8, 13, 14, 2, 2};
     for (int k = 0; k < ncalls; ++k) {
         const int fn = calls[k].fn;
         FR_REQUIRE(fn >= 1 && fn <= 9, "fr_detect_sequence: call %d: unknown function id %d", k, fn);
@@ -51,7 +51,7 @@ extern "C" int fr_detect_sequence(const fr_call* calls, int ncalls) {
                 break;
             case FR_FN_PNET23:
                 rc = fr_pnet23_split_f16(PF(0), sp(c, 1), si(c, 2), si(c, 3), si(c, 4), PF(5), PF(6), PF(7), PF(8), PF(9), PF(10), PF(11), PF(12),
-                                         PFM(13), si(c, 14), sf(c, 15), PIM(16), sp(c, 17), static_cast<size_t>(c.a[18]), sp(c, 19));
+                                         PFM(13), si(c, 14), sf(c, 15), sf(c, 16), PIM(17), sp(c, 18), static_cast<size_t>(c.a[19]), sp(c, 20));
                 break;
             case FR_FN_PNET_CANDIDATES:
                 rc = fr_pnet_candidates(PF(0), si(c, 1), si(c, 2), si(c, 3), sf(c, 4), sf(c, 5), si(c, 6), PFM(7), PFM(8), PFM(9), PIM(10), PIM(11),

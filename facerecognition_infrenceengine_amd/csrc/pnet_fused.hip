@@ -48,6 +48,9 @@ struct P23Args {
     int all_heads;                        // 0: only `dl` is written (the exact pass writes the heads of every cell that can be kept)
     int* list; int* counts; int seg_cap;  // cells with dl >= logit_thr, appended by block b to list[b * seg_cap ..] (counts[b] of them):
     float logit_thr;                      // the work list of the exact pass - no global atomics, no second scan of dl
+    float band_hi;                        // > logit_thr: only cells with logit_thr <= dl <= band_hi go on the list (the band around the
+                                          // face threshold) and every cell with dl >= logit_thr gets its split-precision head row written;
+                                          // otherwise (the default) every cell with dl >= logit_thr is listed: kept cells carry f32 bits
     int B, H1, W1, H3, W3, tiles_x, tiles_y, ntiles;
 };
 
@@ -256,8 +259,10 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
                 const size_t cell = ((size_t)n * a.H3 + gy) * a.W3 + gx;
                 const float4v hb4 = *reinterpret_cast<const float4v*>(cst + 96 + 4 * (fq & 1));
                 const float o0 = d[0] + hb4[0], o1 = d[1] + hb4[1];
+                const float dlv = __shfl(o1 - o0, fr, 64);                  // the pixel's logit difference, on its fq = 1 lane too
+                const bool band = a.band_hi > a.logit_thr;
                 // the exact pass's work list: one LDS atomic per wave and pixel tile that holds a flagged cell
-                const bool flag = inb && fq == 0 && (o1 - o0) >= a.logit_thr;
+                const bool flag = inb && fq == 0 && dlv >= a.logit_thr && (!band || dlv <= a.band_hi);
                 const unsigned long long fm = __ballot(flag);
                 if (fm) {
                     int base = 0;
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
                     if (fq == 0) a.dl[cell] = o1 - o0;
                     // the approximate heads themselves are read by nobody in the product path (fr_pnet_candidates skips the
                     // cells below the margin, the exact pass overwrites the others): 24 B per cell of HBM writes saved
-                    if (a.all_heads) {
+                    if (a.all_heads || (band && dlv >= a.logit_thr)) {
                         float* o = a.head + cell * 6 + 4 * fq;
                         *reinterpret_cast<float2*>(o) = make_float2(o0, o1);
                         if (fq == 0) *reinterpret_cast<float2*>(o + 2) = make_float2(d[2] + hb4[2], d[3] + hb4[3]);
@@ -435,8 +440,8 @@ extern "C" size_t fr_pnet23_workspace_bytes(int B, int H1, int W1) {
 
 extern "C" int fr_pnet23_split_f16(const float* x1, const void* x1s, int B, int H1, int W1, const float* w2, const float* b2,
                                    const float* s2, const float* w3, const float* b3, const float* s3, const float* hw,
-                                   const float* hb, float* head, int all_heads, float refine_logit_thr, int32_t* refined_count,
-                                   void* workspace, size_t workspace_bytes, fr_stream_t stream) {
+                                   const float* hb, float* head, int all_heads, float refine_logit_thr, float refine_band_hi,
+                                   int32_t* refined_count, void* workspace, size_t workspace_bytes, fr_stream_t stream) {
     FR_REQUIRE(x1 && x1s && w2 && b2 && s2 && w3 && b3 && s3 && hw && hb && head, "fr_pnet23_split_f16: null pointer");
     FR_REQUIRE((int64_t)B * H1 * W1 * 64 < (1ll << 31), "fr_pnet23_split_f16: the split conv1 map must stay below 2 GiB (got %lld bytes)", (long long)B * H1 * W1 * 64);
     FR_REQUIRE(B > 0 && H1 >= 5 && W1 >= 5, "fr_pnet23_split_f16: the conv1 map must be at least 5x5 (got %dx%d)", H1, W1);
@@ -454,6 +459,7 @@ extern "C" int fr_pnet23_split_f16(const float* x1, const void* x1s, int B, int 
     a.list = a.counts + 512;
     a.seg_cap = seg_cap;
     a.logit_thr = refine_logit_thr;
+    a.band_hi = refine_band_hi;
     a.ntiles = (int)nt;
     constexpr size_t lds = (size_t)2 * P23_X1PL + (size_t)2 * P23_X2PL + 30 * 1024 + 108 * 4;       // 81,584 B: two blocks per CU
     static FrDevLatch latch;

@@ -156,6 +156,10 @@ class MTCNNHIP:
         self._p23 = tuple(t.to(torch.float32).contiguous().to(d) for t in (
             w2p, p["conv2.bias"], p["prelu2.weight"], w3p, p["conv3.bias"], p["prelu3.weight"], hw.t().contiguous(), hb))
         self.refine_margin = 2e-3           # in logit units, ~200x the split-precision error
+        # Batches of >= 8 frames: only the cells within ``refine_margin`` of the face threshold are re-evaluated exactly (every
+        # keep / reject decision is that of f32 arithmetic); kept cells above the band carry the split-precision heads (~2e-6 from
+        # the f32 ones) - as the R-/O-Net crops do (``split_ro``).  False: every cell that can be kept carries the f32 path's bits.
+        self.pnet_band = True
         self.refined_cells = None           # optional device int32[1]: cells re-evaluated exactly (diagnostics)
         self.p23_all_heads = False          # True: the fused kernel also writes the approximate heads of the cells it rules out
         self.use_sequence = True            # eager single-frame calls of a known frame shape replay a recorded C call list (fr_detect_sequence)
@@ -285,8 +289,11 @@ class MTCNNHIP:
             t0 = self.thresholds[0]
             head = self._f32(N, h - 4, w - 4, 6)
             ws = self._new((self.lib.fr_pnet23_workspace_bytes(N, h, w) // 4,), torch.float32)
+            lt = math.log(t0 / (1.0 - t0))
+            band = self.pnet_band and N >= 8 and trace is None
             self.lib.fr_pnet23_split_f16(_lib.ptr(x), _lib.ptr(xs), N, h, w, *[_lib.ptr(t) for t in self._p23], _lib.ptr(head),
-                                         1 if (self.p23_all_heads or trace is not None) else 0, math.log(t0 / (1.0 - t0)) - self.refine_margin, _lib.ptr(self.refined_cells),
+                                         1 if (self.p23_all_heads or trace is not None) else 0, lt - self.refine_margin,
+                                         lt + self.refine_margin if band else float("-inf"), _lib.ptr(self.refined_cells),
                                          _lib.ptr(ws), ws.numel() * 4, self._s)
             self._dl = (ws, math.log(t0 / (1.0 - t0)) - self.refine_margin)     # pre-filter for fr_pnet_candidates
             return head, h - 4, w - 4

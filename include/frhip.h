@@ -366,14 +366,18 @@ int fr_ro_scatter_rows(const float* src, const int32_t* list, const int32_t* lis
  * b/s: bias and PReLU slope; hw [32][6], hb [6]: conv4_1|conv4_2.  head: f32 [B,H1-4,W1-4,6].
  * all_heads: 0 = only the rows of re-evaluated cells are written (all fr_pnet_candidates reads when it is given the
  * workspace as `dl` and refine_logit_thr as `dl_min`); 1 = the approximate heads of every other cell too (tests, traces).
+ * refine_band_hi: <= refine_logit_thr (pass -INFINITY): as above.  > refine_logit_thr: only the cells with refine_logit_thr <=
+ * logit1 - logit0 <= refine_band_hi - the band around the face threshold, pass ln(t/(1-t)) + 2e-3 - are re-evaluated
+ * exactly (every keep / reject decision is still that of f32 arithmetic); the cells above the band keep their
+ * split-precision rows, which the kernel then writes for every cell >= refine_logit_thr (~2e-6 from the f32 heads).
  * refined_count (optional device i32, accumulated): number of re-evaluated cells.
  * workspace: fr_pnet23_workspace_bytes(B, H1, W1) bytes; its first B*(H1-4)*(W1-4) floats are the logit differences
  * (the `dl` argument of fr_pnet_candidates), behind them the per-block lists of the cells the exact pass re-evaluates. */
 size_t fr_pnet23_workspace_bytes(int B, int H1, int W1);
 int fr_pnet23_split_f16(const float* x1, const void* x1s, int B, int H1, int W1, const float* w2, const float* b2, const float* s2,
                         const float* w3, const float* b3, const float* s3, const float* hw, const float* hb,
-                        float* head, int all_heads, float refine_logit_thr, int32_t* refined_count, void* workspace,
-                        size_t workspace_bytes, fr_stream_t stream);
+                        float* head, int all_heads, float refine_logit_thr, float refine_band_hi, int32_t* refined_count,
+                        void* workspace, size_t workspace_bytes, fr_stream_t stream);
 /* max pool, ceil mode, f32 NHWC */
 int fr_maxpool_f32(const float* x, float* y, int B, int H, int W, int C, int k, int stride,
                    fr_stream_t stream);
@@ -417,7 +421,7 @@ int fr_stage_select(const float* boxes, const float* head, int nh, const int32_t
  * as 8-byte slots in declaration order: pointers and size_t as they are, ints sign-extended, floats as their IEEE bits in
  * the low word.  Two further ids record / wait for an event of the CALLER's (no allocation here): a recorded call may deal
  * the pyramid levels over side streams.  Same kernels, same order per stream, same bits as the individual calls; stops at
- * the first failing call.  `nargs` must be the entry point's arity (18 / 20 / 16 / 18 / 8 / 13 / 14, 2 for the event ids):
+ * the first failing call.  `nargs` must be the entry point's arity (18 / 21 / 16 / 18 / 8 / 13 / 14, 2 for the event ids):
  * a short or malformed entry is refused before anything is launched. */
 enum { FR_FN_DCONV_MFMA = 1, FR_FN_PNET23 = 2, FR_FN_PNET_CANDIDATES = 3, FR_FN_SORT_NMS = 4, FR_FN_BOX_REFINE = 5,
        FR_FN_CROP_CONV1 = 6, FR_FN_STAGE_SELECT = 7,

@@ -570,3 +570,62 @@ def test_split_ro_cascade_vs_f32_cascade_and_exact_pass():
         n = int(want[3][f])
         for a, b in zip(exact[:3], want[:3]):
             assert torch.equal(a[f, :n], b[f, :n])
+
+
+def test_pnet_band_mode_vs_exact_kept_cells():
+    """Batches of >= 8 frames re-evaluate exactly only the P-Net cells within ``refine_margin`` of the face threshold
+    (MTCNNHIP.pnet_band): level by level against the all-f32 path - identical kept-cell sets (the decisions are f32 decisions),
+    the cells inside the band carry the f32 path's bits, the kept cells above it its values to ~1e-5; far fewer cells go
+    through the exact pass than with ``pnet_band = False``; and the whole cascade on eight frames returns the same faces in
+    the same order within 5e-6 (scores) / 1e-3 px of the all-exact setting."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import synth_frame
+    from facerecognition_infrenceengine_amd import weights
+    from facerecognition_infrenceengine_amd.mtcnn import MTCNNHIP, pyramid_scales
+    st = weights.synth_mtcnn_states(seed=4321)
+    band = MTCNNHIP(*st, device="cuda:0")
+    plain = MTCNNHIP(*st, device="cuda:0", fused_pnet=False)
+    exact = MTCNNHIP(*st, device="cuda:0")
+    exact.pnet_band = False
+    band.split_ro = exact.split_ro = plain.split_ro = False           # this test isolates the P-Net
+    band.refined_cells = torch.zeros(1, dtype=torch.int32, device="cuda")
+    exact.refined_cells = torch.zeros(1, dtype=torch.int32, device="cuda")
+    hw = (360, 640)
+    fr = torch.from_numpy(np.ascontiguousarray(np.stack([synth_frame(hw[0], hw[1], 70 + k) for k in range(8)]))).cuda()
+    lt = float(np.log(1.5))
+    kept = inband = 0
+    worst = 0.0
+    for s in pyramid_scales(*hw):
+        with torch.cuda.device("cuda:0"):
+            band._s = plain._s = torch.cuda.current_stream().cuda_stream
+            hb_, h1, w1 = band.pnet_level(fr, s)
+            hp, h2, w2 = plain.pnet_level(fr, s)
+        torch.cuda.synchronize()
+        dp = hp[..., 1] - hp[..., 0]
+        keep_p = dp >= lt
+        dl = band._dl[0][:8 * h1 * w1].reshape(8, h1, w1)
+        cand = dl >= lt - band.refine_margin                              # what fr_pnet_candidates reads
+        assert bool((~cand | (hb_[..., 1] - hb_[..., 0] >= lt) == (~cand | keep_p)).all())       # same decisions on every candidate
+        assert bool((dp[~cand] < lt).all())                               # and nothing the f32 path keeps was ruled out
+        inb = cand & (dl <= lt + band.refine_margin)
+        assert torch.equal(hb_[inb], hp[inb])                             # inside the band: the f32 path's bits
+        if keep_p.any():
+            worst = max(worst, float((hb_[keep_p] - hp[keep_p]).abs().max()))
+        kept += int(keep_p.sum()); inband += int(inb.sum())
+    assert kept >= 100 and worst < 1e-4, (kept, worst)
+    a = band.detect_batch(fr)
+    n_band = int(band.refined_cells[0])
+    b = exact.detect_batch(fr)
+    n_exact = int(exact.refined_cells[0])
+    torch.cuda.synchronize()
+    print(f"\nP-Net band mode: kept {kept} cells, {inband} inside the band; max |head - f32 head| of a kept cell {worst:.2e}; "
+          f"exact pass: {n_band - inband} cells per cascade against {n_exact}")
+    assert n_band - inband < n_exact // 5
+    assert torch.equal(a[3], b[3]) and int(a[3].sum()) >= 8
+    for f in range(8):
+        n = int(a[3][f])
+        if n:
+            assert float((a[1][f, :n] - b[1][f, :n]).abs().max()) <= 5e-6
+            assert float((a[0][f, :n] - b[0][f, :n]).abs().max()) <= 1e-3
+            assert float((a[2][f, :n] - b[2][f, :n]).abs().max()) <= 1e-3

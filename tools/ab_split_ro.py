@@ -1,5 +1,6 @@
-"""Dev tool: a 64 x 1080p detector batch alone with the R-/O-Net second layers on the f32 matrix instruction and on the f16
-matrix cores with split-precision operands (MTCNNHIP.split_ro), phase times by event marks."""
+"""Dev tool: a 64 x 1080p detector batch alone with (a) everything exact (f32 R-/O-Net second layers, every kept P-Net cell
+re-evaluated), (b) + split-precision R-/O-Net conv2 (MTCNNHIP.split_ro), (c) + band-only exact P-Net pass (pnet_band): phase
+times by event marks."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench, warnings
@@ -7,9 +8,10 @@ from facerecognition_infrenceengine_amd import FaceAnalysis
 warnings.simplefilter("ignore")
 app = FaceAnalysis(name="synthetic", arch="r100", cap_o=4).prepare(ctx_id=0)
 frames = bench.synth_frames(64, 1080, 1920, 0, torch.device("cuda:0"))
+app.det.refined_cells = torch.zeros(1, dtype=torch.int32, device="cuda")
 for rep in range(2):
-    for split in (False, True):
-        app.det.split_ro = split
+    for split, band in ((False, False), (True, False), (True, True)):
+        app.det.split_ro, app.det.pnet_band = split, band
         for _ in range(3):
             app.det.detect_batch(frames)
         torch.cuda.synchronize()
@@ -22,13 +24,14 @@ for rep in range(2):
             for (n0, a), (n1, b) in zip(m[:-1], m[1:]):
                 acc[n1] = acc.get(n1, 0.0) + a.elapsed_time(b) / 10
         app.det.phase_marks = None
+        app.det.refined_cells.zero_()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(10):
             out = app.det.detect_batch(frames)
         e1.record(); torch.cuda.synchronize()
-        extra = ""
+        extra = " P-Net cells re-evaluated per batch: %d" % (int(app.det.refined_cells[0]) // 10)
         if split:
-            extra = " exact-pass crops (R, O): %s" % [int(app.det._ro_lists[k][0]) for k in (0, 1)]
-        print("split_ro", split, "detect ms %.3f" % (e0.elapsed_time(e1) / 10), {k: round(v, 3) for k, v in acc.items()},
+            extra += "; exact-pass crops (R, O): %s" % [int(app.det._ro_lists[k][0]) for k in (0, 1)]
+        print("split_ro", split, "pnet_band", band, "detect ms %.3f" % (e0.elapsed_time(e1) / 10), {k: round(v, 3) for k, v in acc.items()},
               "faces", int(out[3].sum()), extra, flush=True)
