@@ -45,6 +45,13 @@ class RolePtr(C.c_void_p):
     role = None
 
 
+class PnetLevel(C.Structure):
+    """One pyramid level of fr_pnet_finish_levels (include/frhip.h fr_pnet_level)."""
+    _fields_ = [("x1", C.c_void_p), ("head", C.c_void_p), ("workspace", C.c_void_p), ("H1", C.c_int), ("W1", C.c_int),
+                ("scale", C.c_float), ("boxes", C.c_void_p), ("scores", C.c_void_p), ("regs", C.c_void_p),
+                ("counts", C.c_void_p), ("block_counts", C.c_void_p)]
+
+
 class Call(C.Structure):
     """One recorded call of fr_detect_sequence: function id + arguments as 8-byte slots (include/frhip.h fr_call)."""
     _fields_ = [("fn", C.c_int32), ("nargs", C.c_int32), ("a", C.c_uint64 * 22)]
@@ -115,6 +122,7 @@ SIGNATURES = {
     "fr_pnet23_workspace_bytes": (_Z, [_I, _I, _I]),
     "fr_pnet23_split_f16": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _Z, _P]),
     "fr_maxpool_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fr_pnet_finish_levels": (_I, [C.POINTER(PnetLevel), _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _F, _P, _P]),
     "fr_pnet_candidates": (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P]),
     "fr_sort_nms": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P, _P, _I, _P]),
     "fr_box_refine": (_I, [_P, _P, _I, _P, _I, _I, _I, _P]),

@@ -276,6 +276,106 @@ __global__ __launch_bounds__(256) void pnet_emit(const float* __restrict__ head,
     }
 }
 
+// All pyramid levels of a batch in one launch each (fr_pnet_finish_levels): a block finds its level in a table in the kernel
+// arguments and runs the per-level kernel's body - the same cells, the same ordered compaction.
+#define PCAND_MAXL 16
+struct PCandLevels {
+    const float* head[PCAND_MAXL]; const float* dl[PCAND_MAXL];
+    float* boxes[PCAND_MAXL]; float* scores[PCAND_MAXL]; float* regs[PCAND_MAXL]; int32_t* counts[PCAND_MAXL]; int32_t* block_counts[PCAND_MAXL];
+    int cells[PCAND_MAXL], wc[PCAND_MAXL], first[PCAND_MAXL + 1];
+    float scale[PCAND_MAXL];
+    int nlevels;
+};
+__global__ __launch_bounds__(256) void pnet_count_levels(PCandLevels t, float thr, float dl_min) {
+    int l = 0;
+    while (l + 1 < t.nlevels && (int)blockIdx.x >= t.first[l + 1]) ++l;
+    const int f = blockIdx.y, b = (int)blockIdx.x - t.first[l], nb = t.first[l + 1] - t.first[l];
+    const int cells = t.cells[l];
+    const int cell = b * 256 + threadIdx.x;
+    bool pass = false;
+    if (cell < cells && t.dl[l][(int64_t)f * cells + cell] >= dl_min) {
+        const float* h = t.head[l] + ((int64_t)f * cells + cell) * 6;
+        pass = softmax2_face(h[0], h[1]) >= thr;
+    }
+    __shared__ int wsum[4];
+    unsigned long long m = __ballot(pass);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) t.block_counts[l][(int64_t)f * nb + b] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ __launch_bounds__(256) void pnet_emit_levels(PCandLevels t, float thr, int cap, float dl_min) {
+    int l = 0;
+    while (l + 1 < t.nlevels && (int)blockIdx.x >= t.first[l + 1]) ++l;
+    const int f = blockIdx.y, b = (int)blockIdx.x - t.first[l], nb = t.first[l + 1] - t.first[l];
+    const int cells = t.cells[l], wc = t.wc[l];
+    const float scale = t.scale[l];
+    const int32_t* block_counts = t.block_counts[l];
+    __shared__ int red[256];
+    __shared__ int wsum[4];
+    int part = 0;
+    for (int i = threadIdx.x; i < b; i += 256) part += block_counts[(int64_t)f * nb + i];
+    red[threadIdx.x] = part;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const int base = red[0];
+    const int cell = b * 256 + threadIdx.x;
+    bool pass = false;
+    float p = 0.f;
+    const float* h = t.head[l] + ((int64_t)f * cells + (cell < cells ? cell : 0)) * 6;
+    if (cell < cells && t.dl[l][(int64_t)f * cells + cell] >= dl_min) {
+        p = softmax2_face(h[0], h[1]);
+        pass = p >= thr;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long m = __ballot(pass);
+    if (lane == 0) wsum[wv] = __popcll(m);
+    __syncthreads();
+    int woff = 0;
+    for (int i = 0; i < wv; ++i) woff += wsum[i];
+    const int rank = base + woff + __popcll(m & ((1ull << lane) - 1ull));
+    if (pass && rank < cap) {
+        const int cy = cell / wc, cx = cell - cy * wc;
+        const int64_t o = (int64_t)f * cap + rank;
+        float4 bx;
+        bx.x = floorf((2.0f * (float)cx + 1.0f) / scale);
+        bx.y = floorf((2.0f * (float)cy + 1.0f) / scale);
+        bx.z = floorf((2.0f * (float)cx + 12.0f) / scale);
+        bx.w = floorf((2.0f * (float)cy + 12.0f) / scale);
+        *reinterpret_cast<float4*>(t.boxes[l] + o * 4) = bx;
+        t.scores[l][o] = p;
+        *reinterpret_cast<float4*>(t.regs[l] + o * 4) = make_float4(h[2], h[3], h[4], h[5]);
+    }
+    if (b == nb - 1 && threadIdx.x == 0) {
+        int total = base + wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        t.counts[l][f] = total < cap ? total : cap;
+    }
+}
+
+int fr_pnet_candidates_levels_launch(const fr_pnet_level* lv, int nlevels, int nframes, float thr, int cap, float dl_min, hipStream_t s) {
+    PCandLevels t;
+    t.nlevels = nlevels;
+    int total = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        const int hc = lv[l].H1 - 4, wc = lv[l].W1 - 4;
+        t.head[l] = lv[l].head; t.dl[l] = reinterpret_cast<const float*>(lv[l].workspace);
+        t.boxes[l] = lv[l].boxes; t.scores[l] = lv[l].scores; t.regs[l] = lv[l].regs; t.counts[l] = lv[l].counts;
+        t.block_counts[l] = lv[l].block_counts;
+        t.cells[l] = hc * wc; t.wc[l] = wc; t.scale[l] = lv[l].scale;
+        t.first[l] = total;
+        total += fr_cdiv(hc * wc, 256);
+    }
+    t.first[nlevels] = total;
+    dim3 grid(total, nframes);
+    pnet_count_levels<<<grid, 256, 0, s>>>(t, thr, dl_min);
+    FR_CHECK_LAUNCH("pnet_count_levels");
+    pnet_emit_levels<<<grid, 256, 0, s>>>(t, thr, cap, dl_min);
+    FR_CHECK_LAUNCH("pnet_emit_levels");
+    return FR_OK;
+}
+
 extern "C" int fr_pnet_candidates(const float* head, int nframes, int hc, int wc, float scale, float thr, int cap,
                                   float* boxes, float* scores, float* regs, int32_t* counts, int32_t* block_counts,
                                   float* prob_out, const float* dl, float dl_min, fr_stream_t stream) {

@@ -309,14 +309,12 @@ struct PRefArgs {
     int* counter;                                          // optional: accumulated number of re-evaluated cells (diagnostics), or NULL
 };
 
-__global__ __launch_bounds__(256, 2) void pnet_refine_mfma(PRefArgs a) {
+__device__ __forceinline__ void pnet_refine_body(const PRefArgs& a, const int block, float (*wins)[16 * PREF_WS], int (*cbase)[16]) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(16))) float wins[4][16 * PREF_WS];          // per wave: 16 cells' windows, then their conv2 tiles
-    __shared__ int cbase[4][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     float* win = wins[wave];
-    if (a.counts[blockIdx.x] == 0) return;                  // block-uniform, before any barrier
+    if (a.counts[block] == 0) return;                       // block-uniform, before any barrier
     // ---- weights as A operands: lane (row li, k slot kq)
     float wa2[27], wa3[2][36], hwa[8];
 #pragma unroll
@@ -341,8 +339,8 @@ __global__ __launch_bounds__(256, 2) void pnet_refine_mfma(PRefArgs a) {
 
     const int hw3 = a.H3 * a.W3;
     {
-        const int* lst = a.list + (size_t)blockIdx.x * a.seg_cap;
-        const int n_list = a.counts[blockIdx.x];
+        const int* lst = a.list + (size_t)block * a.seg_cap;
+        const int n_list = a.counts[block];
         if (a.counter && tid == 0 && n_list) atomicAdd(a.counter, n_list);
         // wave w takes the cells [i0 + 16 w, + 16) of the list; slots past its end repeat the last cell and store nothing
         for (int i0 = wave * 16; i0 < n_list; i0 += 64) {
@@ -423,6 +421,30 @@ __global__ __launch_bounds__(256, 2) void pnet_refine_mfma(PRefArgs a) {
 #endif
 }
 
+__global__ __launch_bounds__(256, 2) void pnet_refine_mfma(PRefArgs a) {
+    __shared__ __attribute__((aligned(16))) float wins[4][16 * PREF_WS];          // per wave: 16 cells' windows, then their conv2 tiles
+    __shared__ int cbase[4][16];
+    pnet_refine_body(a, blockIdx.x, wins, cbase);
+}
+
+// The same pass for ALL pyramid levels of a batch in one launch (fr_pnet_finish_levels): with the band-only list a level
+// holds a few hundred cells at most and twelve launches sat on their ~21 us floor one after the other.
+#define PREF_MAXL 16
+struct PRefLevels {
+    const float* x1[PREF_MAXL]; float* head[PREF_MAXL]; const int* list[PREF_MAXL]; const int* counts[PREF_MAXL];
+    int seg_cap[PREF_MAXL], H1[PREF_MAXL], W1[PREF_MAXL], first[PREF_MAXL + 1];        // first[l]: the level's first block
+    int nlevels;
+};
+__global__ __launch_bounds__(256, 2) void pnet_refine_levels(PRefArgs a, PRefLevels t) {
+    __shared__ __attribute__((aligned(16))) float wins[4][16 * PREF_WS];
+    __shared__ int cbase[4][16];
+    int l = 0;
+    while (l + 1 < t.nlevels && (int)blockIdx.x >= t.first[l + 1]) ++l;
+    a.x1 = t.x1[l]; a.head = t.head[l]; a.list = t.list[l]; a.counts = t.counts[l]; a.seg_cap = t.seg_cap[l];
+    a.H1 = t.H1[l]; a.W1 = t.W1[l]; a.H3 = t.H1[l] - 4; a.W3 = t.W1[l] - 4;
+    pnet_refine_body(a, (int)blockIdx.x - t.first[l], wins, cbase);
+}
+
 // workspace of fr_pnet23_split_f16: [dl: one float per cell][counts: 512 ints][lists: one segment per block]
 static void p23_layout(int B, int H1, int W1, long long& ncell, long long& ntiles, int& grid, int& seg_cap) {
     const int H3 = H1 - 4, W3 = W1 - 4;
@@ -446,7 +468,7 @@ extern "C" int fr_pnet23_split_f16(const float* x1, const void* x1s, int B, int 
     FR_REQUIRE((int64_t)B * H1 * W1 * 64 < (1ll << 31), "fr_pnet23_split_f16: the split conv1 map must stay below 2 GiB (got %lld bytes)", (long long)B * H1 * W1 * 64);
     FR_REQUIRE(B > 0 && H1 >= 5 && W1 >= 5, "fr_pnet23_split_f16: the conv1 map must be at least 5x5 (got %dx%d)", H1, W1);
     P23Args a;
-    a.x1 = x1; a.x1s = (const unsigned char*)x1s; a.x1s_bytes = (unsigned)((int64_t)B * H1 * W1 * 64); a.w2 = w2; a.b2 = b2; a.s2 = s2; a.w3 = w3; a.b3 = b3; a.s3 = s3; a.hw = hw; a.hb = hb; a.head = head; a.all_heads = all_heads;
+    a.x1 = x1; a.x1s = (const unsigned char*)x1s; a.x1s_bytes = (unsigned)((int64_t)B * H1 * W1 * 64); a.w2 = w2; a.b2 = b2; a.s2 = s2; a.w3 = w3; a.b3 = b3; a.s3 = s3; a.hw = hw; a.hb = hb; a.head = head; a.all_heads = all_heads & 1;
     a.B = B; a.H1 = H1; a.W1 = W1; a.H3 = H1 - 4; a.W3 = W1 - 4;
     a.tiles_x = (a.W3 + P23_RW - 1) / P23_RW; a.tiles_y = (a.H3 + P23_RH - 1) / P23_RH;
     long long ncell, nt; int grid, seg_cap;
@@ -467,6 +489,7 @@ extern "C" int fr_pnet23_split_f16(const float* x1, const void* x1s, int B, int 
     hipStream_t s = fr_stream(stream);
     pnet23_split_f16<<<grid, P23_NT, lds, s>>>(a);
     FR_CHECK_LAUNCH("pnet23_split_f16");
+    if (all_heads & 2) return FR_OK;                        // the exact pass of every level follows in ONE launch: fr_pnet_finish_levels
     PRefArgs r;
     r.x1 = x1; r.w2 = w2; r.b2 = b2; r.s2 = s2; r.w3 = w3; r.b3 = b3; r.s3 = s3; r.hw = hw; r.hb = hb; r.head = head;
     r.list = a.list; r.counts = a.counts; r.seg_cap = seg_cap;
@@ -474,4 +497,38 @@ extern "C" int fr_pnet23_split_f16(const float* x1, const void* x1s, int B, int 
     pnet_refine_mfma<<<grid, 256, 0, s>>>(r);              // block b takes the list of pnet23's block b
     FR_CHECK_LAUNCH("pnet_refine_mfma");
     return FR_OK;
+}
+
+// ---------------------------------------------------------------- all levels of a batch: exact pass + candidates in three launches
+int fr_pnet_candidates_levels_launch(const fr_pnet_level* lv, int nlevels, int nframes, float thr, int cap, float dl_min, hipStream_t s);
+
+extern "C" int fr_pnet_finish_levels(const fr_pnet_level* levels, int nlevels, int nframes, const float* w2, const float* b2,
+                                     const float* s2, const float* w3, const float* b3, const float* s3, const float* hw,
+                                     const float* hb, float thr, int cap, float dl_min, int32_t* refined_count, fr_stream_t stream) {
+    FR_REQUIRE(levels && nlevels > 0 && nlevels <= PREF_MAXL && nframes > 0 && cap > 0, "fr_pnet_finish_levels: 1 .. %d levels", PREF_MAXL);
+    FR_REQUIRE(w2 && b2 && s2 && w3 && b3 && s3 && hw && hb, "fr_pnet_finish_levels: null pointer");
+    PRefLevels t;
+    t.nlevels = nlevels;
+    int total = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        const fr_pnet_level& L = levels[l];
+        FR_REQUIRE(L.x1 && L.head && L.workspace && L.boxes && L.scores && L.regs && L.counts && L.block_counts && L.H1 >= 5 && L.W1 >= 5 && L.scale > 0.f,
+                   "fr_pnet_finish_levels: level %d: bad entry", l);
+        long long ncell, nt; int grid, seg_cap;
+        p23_layout(nframes, L.H1, L.W1, ncell, nt, grid, seg_cap);
+        float* dl = reinterpret_cast<float*>(L.workspace);
+        const int* counts = reinterpret_cast<const int*>(dl + ncell);
+        t.x1[l] = L.x1; t.head[l] = L.head; t.counts[l] = counts; t.list[l] = counts + 512;
+        t.seg_cap[l] = seg_cap; t.H1[l] = L.H1; t.W1[l] = L.W1;
+        t.first[l] = total;
+        total += grid;
+    }
+    t.first[nlevels] = total;
+    PRefArgs r;
+    r.x1 = nullptr; r.w2 = w2; r.b2 = b2; r.s2 = s2; r.w3 = w3; r.b3 = b3; r.s3 = s3; r.hw = hw; r.hb = hb; r.head = nullptr;
+    r.list = nullptr; r.counts = nullptr; r.seg_cap = 0; r.B = nframes; r.H1 = r.W1 = r.H3 = r.W3 = 0; r.counter = refined_count;
+    hipStream_t s = fr_stream(stream);
+    pnet_refine_levels<<<total, 256, 0, s>>>(r, t);
+    FR_CHECK_LAUNCH("pnet_refine_levels");
+    return fr_pnet_candidates_levels_launch(levels, nlevels, nframes, thr, cap, dl_min, s);
 }

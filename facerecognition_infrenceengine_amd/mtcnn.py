@@ -160,6 +160,10 @@ class MTCNNHIP:
         # keep / reject decision is that of f32 arithmetic); kept cells above the band carry the split-precision heads (~2e-6 from
         # the f32 ones) - as the R-/O-Net crops do (``split_ro``).  False: every cell that can be kept carries the f32 path's bits.
         self.pnet_band = True
+        # exact pass + candidates of ALL levels in three launches behind the pyramid (fr_pnet_finish_levels) instead of three per
+        # level.  Measured (64 x 1080p, same box): 5.92 - 5.95 ms against 5.77 - 5.80 per level - the per-level launches ride on
+        # their level's stream under the other levels' kernels, the merged ones come behind the join.  Off; kept as an option.
+        self.finish_levels = False
         self.refined_cells = None           # optional device int32[1]: cells re-evaluated exactly (diagnostics)
         self.p23_all_heads = False          # True: the fused kernel also writes the approximate heads of the cells it rules out
         self.use_sequence = True            # eager single-frame calls of a known frame shape replay a recorded C call list (fr_detect_sequence)
@@ -291,11 +295,14 @@ class MTCNNHIP:
             ws = self._new((self.lib.fr_pnet23_workspace_bytes(N, h, w) // 4,), torch.float32)
             lt = math.log(t0 / (1.0 - t0))
             band = self.pnet_band and N >= 8 and trace is None
+            defer = getattr(self._tls, "defer", None)     # detect_batch: the exact pass of every level in one launch, behind the pyramid
             self.lib.fr_pnet23_split_f16(_lib.ptr(x), _lib.ptr(xs), N, h, w, *[_lib.ptr(t) for t in self._p23], _lib.ptr(head),
-                                         1 if (self.p23_all_heads or trace is not None) else 0, lt - self.refine_margin,
-                                         lt + self.refine_margin if band else float("-inf"), _lib.ptr(self.refined_cells),
-                                         _lib.ptr(ws), ws.numel() * 4, self._s)
+                                         (1 if (self.p23_all_heads or trace is not None) else 0) | (2 if defer is not None else 0),
+                                         lt - self.refine_margin, lt + self.refine_margin if band else float("-inf"),
+                                         _lib.ptr(self.refined_cells), _lib.ptr(ws), ws.numel() * 4, self._s)
             self._dl = (ws, math.log(t0 / (1.0 - t0)) - self.refine_margin)     # pre-filter for fr_pnet_candidates
+            if defer is not None:
+                defer.append((x, head, ws, h, w))
             return head, h - 4, w - 4
         self._dl = (None, 0.0)
         x, h, w = self._dconv(None, self.p1, N, hs, ws, frames=frames)
@@ -408,6 +415,7 @@ class MTCNNHIP:
             self._s = _lib.stream_ptr()
             self._tls.cache = None              # (a call that raised may have left these set)
             self._tls.cache_grew = False
+            self._tls.defer = None
             self.lib.stop_recording()
             self._mark("start")
             scales = pyramid_scales(H, W, self.minsize, self.factor)
@@ -490,6 +498,14 @@ class MTCNNHIP:
             if not solo:
                 for side in sides:
                     side.wait_stream(main)
+            # Batches: the exact pass and the candidate extraction of ALL levels run as three launches behind the pyramid
+            # (fr_pnet_finish_levels) instead of three per level - with the band-only exact pass a level's launches sat on
+            # their latency floor, twelve levels one after the other
+            finish = (N >= 8 and trace is None and self.fused_pnet and self.merged_level_nms and self.finish_levels and nlev <= 16
+                      and all(N * self.p1.out_hw(int(math.ceil(H * sc)), int(math.ceil(W * sc)))[0]
+                              * self.p1.out_hw(int(math.ceil(H * sc)), int(math.ceil(W * sc)))[1] * 64 < 2 ** 31 for sc in scales))
+            self._tls.defer = [] if finish else None
+            bcs = []
             for li, s in enumerate(scales):
                 side = sides[(li - 1) % len(sides)] if li else sides[0]
                 with (contextlib.nullcontext() if solo else torch.cuda.stream(main if li == 0 else side)):
@@ -502,9 +518,12 @@ class MTCNNHIP:
                     bc = self._i32(N * nblk)
                     prob = self._f32(N, hc, wc) if trace is not None else None
                     dl, dl_min = self._dl
-                    lib.fr_pnet_candidates(_lib.ptr(head), N, hc, wc, float(s), t0, cs, _lib.ptr(lb[li]), _lib.ptr(ls[li]),
-                                           _lib.ptr(lr[li]), _lib.ptr(lc[li]), _lib.ptr(bc), _lib.ptr(prob), _lib.ptr(dl),
-                                           dl_min, self._s)
+                    if finish:
+                        bcs.append(bc)
+                    else:
+                        lib.fr_pnet_candidates(_lib.ptr(head), N, hc, wc, float(s), t0, cs, _lib.ptr(lb[li]), _lib.ptr(ls[li]),
+                                               _lib.ptr(lr[li]), _lib.ptr(lc[li]), _lib.ptr(bc), _lib.ptr(prob), _lib.ptr(dl),
+                                               dl_min, self._s)
                     # per-level NMS 0.5 -> keep_scale survivors: one launch for all levels behind the loop (default), or
                     # right behind the level's own kernels on the level's stream (merged_level_nms False, batches only)
                     if N >= 8 and not self.merged_level_nms:
@@ -523,6 +542,16 @@ class MTCNNHIP:
                     main.wait_event(ev)
                     lib.note(9, main.cuda_stream, ev.cuda_event)
                 self._s = ctypes.c_void_p(main.cuda_stream)
+            if finish:
+                lv = (_lib.PnetLevel * nlev)()
+                for li, ((x1, head, ws, h1, w1), bc, sc) in enumerate(zip(self._tls.defer, bcs, scales)):
+                    for t in (x1, head, ws, bc):
+                        t.record_stream(main)               # allocated on a level stream, read here
+                    lv[li] = _lib.PnetLevel(x1.data_ptr(), head.data_ptr(), ws.data_ptr(), h1, w1, float(sc), lb[li].data_ptr(),
+                                            ls[li].data_ptr(), lr[li].data_ptr(), lc[li].data_ptr(), bc.data_ptr())
+                lib.fr_pnet_finish_levels(lv, nlev, N, *[_lib.ptr(t) for t in self._p23], t0, cs, self._dl[1],
+                                          _lib.ptr(self.refined_cells), self._s)
+                self._tls.defer = None
             self._mark("pnet")
             if N < 8 or self.merged_level_nms:
                 self._nms(lb, ls, lr, 4, lc, nlev * N, 1, cs, 0, 0.5, 0, ksz, out=(kb, ks, ka, kc))

@@ -372,7 +372,8 @@ int fr_ro_scatter_rows(const float* src, const int32_t* list, const int32_t* lis
  * split-precision rows, which the kernel then writes for every cell >= refine_logit_thr (~2e-6 from the f32 heads).
  * refined_count (optional device i32, accumulated): number of re-evaluated cells.
  * workspace: fr_pnet23_workspace_bytes(B, H1, W1) bytes; its first B*(H1-4)*(W1-4) floats are the logit differences
- * (the `dl` argument of fr_pnet_candidates), behind them the per-block lists of the cells the exact pass re-evaluates. */
+ * (the `dl` argument of fr_pnet_candidates), behind them the per-block lists of the cells the exact pass re-evaluates.
+ * all_heads bit 1 (value 2): the exact pass is NOT launched here - fr_pnet_finish_levels runs it for every level at once. */
 size_t fr_pnet23_workspace_bytes(int B, int H1, int W1);
 int fr_pnet23_split_f16(const float* x1, const void* x1s, int B, int H1, int W1, const float* w2, const float* b2, const float* s2,
                         const float* w3, const float* b3, const float* s3, const float* hw, const float* hb,
@@ -415,6 +416,19 @@ int fr_crop_resize_norm(const uint8_t* frames, int nframes, int H, int W, const 
 int fr_stage_select(const float* boxes, const float* head, int nh, const int32_t* counts, int L, int cap,
                     float thr, float* boxes_out, float* scores_out, float* aux_out, int naux,
                     int32_t* counts_out, float* prob_out, fr_stream_t stream);
+
+/* The exact pass (deferred by all_heads bit 1) and fr_pnet_candidates for ALL pyramid levels of a batch in three launches
+ * instead of three per level: the same cells, the same ordered compaction per level and frame.  A level entry repeats what
+ * its fr_pnet23_split_f16 / fr_pnet_candidates calls would have been given (workspace = that level's, unchanged since;
+ * block_counts: i32 [nframes * ceil((H1-4)*(W1-4)/256)]).  At most 16 levels. */
+typedef struct {
+    const float* x1; float* head; void* workspace;
+    int H1, W1; float scale;
+    float* boxes; float* scores; float* regs; int32_t* counts; int32_t* block_counts;
+} fr_pnet_level;
+int fr_pnet_finish_levels(const fr_pnet_level* levels, int nlevels, int nframes, const float* w2, const float* b2,
+                          const float* s2, const float* w3, const float* b3, const float* s3, const float* hw,
+                          const float* hb, float thr, int cap, float dl_min, int32_t* refined_count, fr_stream_t stream);
 
 /* A recorded run of detector calls replayed by ONE C call (an eager single-frame get() is bound by the interpreter: ~50
  * ctypes calls per frame; FaceAnalysis.get, infrenceServer.py:528).  `fn` names the entry point, `a` carries its arguments

@@ -629,3 +629,35 @@ def test_pnet_band_mode_vs_exact_kept_cells():
             assert float((a[1][f, :n] - b[1][f, :n]).abs().max()) <= 5e-6
             assert float((a[0][f, :n] - b[0][f, :n]).abs().max()) <= 1e-3
             assert float((a[2][f, :n] - b[2][f, :n]).abs().max()) <= 1e-3
+
+
+def test_all_levels_in_three_launches_equal_per_level_launches():
+    """Batches CAN run the P-Net's exact pass and candidate extraction for ALL pyramid levels in three launches
+    (fr_pnet_finish_levels, MTCNNHIP.finish_levels; off by default: measured slower) instead of three per level: the same cells, the same ordered compaction -
+    the cascade's results are bit-identical to the per-level launches, with the band-only exact pass and with every kept cell
+    re-evaluated, also for a batch whose frames hold no candidate at some levels."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import synth_frame
+    from facerecognition_infrenceengine_amd import weights
+    from facerecognition_infrenceengine_amd.mtcnn import MTCNNHIP
+    st = weights.synth_mtcnn_states(seed=4321)
+    one = MTCNNHIP(*st, device="cuda:0")
+    per = MTCNNHIP(*st, device="cuda:0")
+    one.finish_levels, per.finish_levels = True, False
+    one.refined_cells = torch.zeros(1, dtype=torch.int32, device="cuda")
+    per.refined_cells = torch.zeros(1, dtype=torch.int32, device="cuda")
+    frs = np.ascontiguousarray(np.stack([synth_frame(300, 500, 80 + k) for k in range(9)]))
+    frs[4] = 0
+    x = torch.from_numpy(frs).cuda()
+    for band in (True, False):
+        one.pnet_band = per.pnet_band = band
+        one.refined_cells.zero_(); per.refined_cells.zero_()
+        a, b = one.detect_batch(x), per.detect_batch(x)
+        torch.cuda.synchronize()
+        assert torch.equal(a[3], b[3]) and int(a[3].sum()) >= 8 and int(a[3][4]) == 0
+        assert int(one.refined_cells[0]) == int(per.refined_cells[0]) > 0
+        for f in range(9):
+            n = int(a[3][f])
+            for u, v in zip(a[:3], b[:3]):
+                assert torch.equal(u[f, :n], v[f, :n])
