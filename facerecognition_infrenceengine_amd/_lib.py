@@ -117,6 +117,9 @@ SIGNATURES = {
     "fr_crop_conv1_split": (_I, [_I, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P]),
     "fr_crop_conv1_list_f32": (_I, [_I, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P]),
     "fr_ro_conv2_split": (_I, [_I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
+    "fr_ro_gemm_weight_bytes": (_Z, [_I]),
+    "fr_ro_gemm_pack": (_I, [_I, _P, _P, _P]),
+    "fr_ro_gemm_split": (_I, [_I, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     "fr_ro_margin_list": (_I, [_P, _I, _P, _I, _I, _F, _F, _P, _P, _I, _P]),
     "fr_ro_scatter_rows": (_I, [_P, _P, _P, _I, _I, _P, _P]),
     "fr_pnet23_workspace_bytes": (_Z, [_I, _I, _I]),

@@ -177,6 +177,7 @@ class MTCNNHIP:
         # weights as [cout][tap][32 channels] f32; the crops whose logit lies within ``ro_margin`` of the stage threshold are
         # re-evaluated by the all-f32 layers, so every keep / reject decision is that of f32 arithmetic
         self.split_ro = True
+        self.split_tail = True              # with split_ro: conv3 / dense4 (R-Net), conv4 / dense5 (O-Net) as split-precision GEMMs too
         self.ro_margin = 1e-3               # in logit units; the split path's measured head error is ~1e-6
         self.ro_list_cap = (1024, 256)      # slots of the exact pass's work list (R-Net, O-Net); entries past it keep the split values
         def c2w(w):
@@ -197,6 +198,19 @@ class MTCNNHIP:
         self.o3 = _MConv(22, o["conv3.weight"], o["conv3.bias"], o["prelu3.weight"], d)
         self.o4 = _MConv(23, o["conv4.weight"], o["conv4.bias"], o["prelu4.weight"], d)
         self.o5 = _MConv(24, _dense_as_conv(o["dense5.weight"], 3, 128), o["dense5.bias"], o["prelu5.weight"], d)
+        # the small tail layers as split-precision GEMMs on the f16 matrix cores (csrc/ro_gemm.hip; batch path): f32 weights
+        # [cout][K], K = (kh, kw, channel) ascending = the input map's memory order, packed into MFMA fragment order
+        self._gemm = {}
+        for lid, wconv, b, sl in ((12, r["conv3.weight"], r["conv3.bias"], r["prelu3.weight"]),
+                                  (13, _dense_as_conv(r["dense4.weight"], 3, 64), r["dense4.bias"], r["prelu4.weight"]),
+                                  (23, o["conv4.weight"], o["conv4.bias"], o["prelu4.weight"]),
+                                  (24, _dense_as_conv(o["dense5.weight"], 3, 128), o["dense5.bias"], o["prelu5.weight"])):
+            wk = wconv.permute(0, 2, 3, 1).reshape(wconv.shape[0], -1).to(torch.float32).contiguous().to(d)
+            packed = torch.empty(self.lib.fr_ro_gemm_weight_bytes(lid), dtype=torch.uint8, device=d)
+            with torch.cuda.device(d):
+                self.lib.fr_ro_gemm_pack(lid, _lib.ptr(wk), _lib.ptr(packed), _lib.stream_ptr())
+                torch.cuda.synchronize(d)
+            self._gemm[lid] = (packed, b.to(torch.float32).contiguous().to(d), sl.to(torch.float32).contiguous().to(d))
         self.o6 = _MConv(25, torch.cat([o["dense6_1.weight"], o["dense6_2.weight"], o["dense6_3.weight"]]).reshape(16, 256, 1, 1),
                          torch.cat([o["dense6_1.bias"], o["dense6_2.bias"], o["dense6_3.bias"]]), None, d)
 
@@ -260,6 +274,12 @@ class MTCNNHIP:
                                   c.cin, c.cout, c.coutp, c.kh, c.kw, 1 if c.pool2 else 0, _lib.ptr(c.head_w),
                                   _lib.ptr(c.head_b), c.nhead, self._s)
         return y, ho, wo
+
+    def _gemm_split(self, lid, x, B, shape, counts, cap):
+        w, b, sl = self._gemm[lid]
+        y = self._f32(B, *shape)
+        self.lib.fr_ro_gemm_split(lid, _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(sl), _lib.ptr(y), B, _lib.ptr(counts), cap, self._s)
+        return y
 
     def _pool(self, x, B, H, W, C, k, s):
         ho, wo = _pool_out(H, k, s), _pool_out(W, k, s)
@@ -367,8 +387,12 @@ class MTCNNHIP:
             x, h, w = self._dconv(x, self.r1, B, 24, 24, **k)   # + fused 3x3/s2 pool -> 11x11
         if x2 is None:
             x, h, w = self._dconv(x, self.r2, B, h, w, **k)     # + fused 3x3/s2 pool -> 4x4
-        x, h, w = self._dconv(x, self.r3, B, h, w, **k)
-        x, h, w = self._dconv(x, self.r4, B, h, w, **k)
+        if x2 is not None and self.split_tail:               # the batch path: conv3 / dense4 as split-precision GEMMs
+            x = self._gemm_split(12, x, B, (3, 3, 64), counts, cap)
+            x = self._gemm_split(13, x, B, (1, 1, 128), counts, cap)
+        else:
+            x, h, w = self._dconv(x, self.r3, B, h, w, **k)
+            x, h, w = self._dconv(x, self.r4, B, h, w, **k)
         x, h, w = self._dconv(x, self.r5, B, 1, 1, **k)
         return x.reshape(B, 6)
 
@@ -383,8 +407,12 @@ class MTCNNHIP:
         if x2 is None:
             x, h, w = self._dconv(x, self.o2, B, h, w, **k)     # + fused 3x3/s2 pool -> 10x10
         x, h, w = self._dconv(x, self.o3, B, h, w, **k)     # + fused 2x2/s2 pool -> 4x4
-        x, h, w = self._dconv(x, self.o4, B, h, w, **k)
-        x, h, w = self._dconv(x, self.o5, B, h, w, **k)
+        if x2 is not None and self.split_tail:
+            x = self._gemm_split(23, x, B, (3, 3, 128), counts, cap)
+            x = self._gemm_split(24, x, B, (1, 1, 256), counts, cap)
+        else:
+            x, h, w = self._dconv(x, self.o4, B, h, w, **k)
+            x, h, w = self._dconv(x, self.o5, B, h, w, **k)
         x, h, w = self._dconv(x, self.o6, B, 1, 1, **k)
         return x.reshape(B, 16)
 

@@ -347,6 +347,16 @@ int fr_crop_conv1_list_f32(int net, const uint8_t* frames, int nframes, int H, i
  * the fr_ro_margin_list call that follows in the stream (saves a memset launch). */
 int fr_ro_conv2_split(int net, const void* x_split, const float* w, const float* bias, const float* slope, float* y,
                       int nslots, const int32_t* counts, int cap, int32_t* zero_word, fr_stream_t stream);
+/* The small tail layers of R-Net / O-Net as one split-precision GEMM kernel on the f16 matrix cores (x = hi + lo in f16,
+ * three MFMAs per product term, f32 accumulate; ~1e-6 of the output's scale from the f32 layers): layer 12 = R-Net conv3
+ * (2x2, 48 -> 64, [.,4,4,48] -> [.,3,3,64]), 13 = R-Net dense4 ([.,3,3,64] -> [.,128]), 23 = O-Net conv4 (2x2, 64 -> 128,
+ * [.,4,4,64] -> [.,3,3,128]), 24 = O-Net dense5 ([.,3,3,128] -> [.,256]) - the layers of the same ids of fr_dconv_mfma_f32,
+ * + bias + PReLU.  w_packed: fr_ro_gemm_pack(layer, w) of the f32 weights [Cout][K], K = (kh, kw, channel) ascending
+ * (fr_ro_gemm_weight_bytes(layer) bytes).  counts / cap as fr_dconv_mfma_f32.  Batch path only: see fr_ro_conv2_split. */
+size_t fr_ro_gemm_weight_bytes(int layer);
+int fr_ro_gemm_pack(int layer, const float* w, void* out, fr_stream_t stream);
+int fr_ro_gemm_split(int layer, const float* x, const void* w_packed, const float* bias, const float* slope, float* y,
+                     int nslots, const int32_t* counts, int cap, fr_stream_t stream);
 /* The exact pass's work list: the valid slots whose logit difference head[s][1] - head[s][0] lies within `margin` of
  * logit_thr = ln(t / (1 - t)) (t: the stage's probability threshold) are appended to list (any order); *list_count = how
  * many there are (may exceed list_cap: entries past it are dropped, consumers clamp).  head f32 [nframes*cap][nhead].

@@ -661,3 +661,28 @@ def test_all_levels_in_three_launches_equal_per_level_launches():
             n = int(a[3][f])
             for u, v in zip(a[:3], b[:3]):
                 assert torch.equal(u[f, :n], v[f, :n])
+
+
+def test_split_gemm_tail_layers_vs_f32_layers():
+    """R-Net conv3 / dense4 and O-Net conv4 / dense5 as split-precision GEMMs on the f16 matrix cores (csrc/ro_gemm.hip) against
+    the f32 layers of the same ids (fr_dconv_mfma_f32) on random maps: ~1e-6 of the output's scale on every valid slot, with
+    partially filled and empty frames and a slot count that is no multiple of the kernel's 64-row tiles."""
+    from facerecognition_infrenceengine_amd import _lib, weights
+    from facerecognition_infrenceengine_amd.mtcnn import MTCNNHIP
+    d = MTCNNHIP(*weights.synth_mtcnn_states(seed=79), device="cuda:0")
+    d._s = _lib.stream_ptr()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    N, cap = 5, 30
+    counts = torch.tensor([cap, 7, 0, 19, 1], dtype=torch.int32, device="cuda")
+    valid = (torch.arange(cap, device="cuda")[None, :] < counts[:, None]).reshape(-1)
+    B = N * cap
+    for lid, layer, shape_in, shape_out in ((12, d.r3, (4, 4, 48), (3, 3, 64)), (13, d.r4, (3, 3, 64), (1, 1, 128)),
+                                            (23, d.o4, (4, 4, 64), (3, 3, 128)), (24, d.o5, (3, 3, 128), (1, 1, 256))):
+        x = torch.randn((B, *shape_in), generator=g, device="cuda") * 1.5
+        want, _, _ = d._dconv(x, layer, B, shape_in[0], shape_in[1], counts=counts, cap=cap)
+        got = d._gemm_split(lid, x, B, shape_out, counts, cap)
+        torch.cuda.synchronize()
+        assert got.shape == want.shape == (B, *shape_out)
+        err, scale = float((got[valid] - want[valid]).abs().max()), float(want[valid].abs().max())
+        print(f"\nlayer {lid}: split GEMM vs f32 layer: max |d| {err:.3e} at scale {scale:.3f}")
+        assert err <= 4e-6 * scale, (lid, err, scale)
