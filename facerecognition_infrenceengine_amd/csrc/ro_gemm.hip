@@ -1,5 +1,5 @@
-// The small tail layers of MTCNN's R-Net / O-Net - conv 2x2 on a 4x4 map and the dense layers (R-Net conv3 48 -> 64 and
-// dense4 576 -> 128, O-Net conv4 64 -> 128 and dense5 1152 -> 256; detector half of FaceAnalysis.get,
+// The small tail layers of MTCNN's R-Net / O-Net - conv 2x2 on a 4x4 map, the dense layers and the O-Net's third conv (R-Net
+// conv3 48 -> 64 and dense4 576 -> 128, O-Net conv3 64 -> 64 + pool, conv4 64 -> 128 and dense5 1152 -> 256; detector half of FaceAnalysis.get,
 // /root/reference/infrenceServer.py:528) - as ONE split-precision GEMM kernel on the f16 matrix cores.
 //
 // Why: on the f32 matrix instruction these four launches were 0.36 ms of a 64 x 1080p detector batch (32 768 R-Net and 4 096
@@ -30,12 +30,17 @@ struct RgArgs {
     int nslots;
 };
 
-// L: floats of one kernel row's run (KW * Cin); KH runs per row; N couts; HIN x WIN input map of CIN channels; output HO x WO
-template <int L, int KH, int N, int HIN, int WIN, int CIN, int HO, int WO>
+// L: floats of one kernel row's run (KW * Cin); KH runs per row; N couts, NB of them per block (blockIdx.y picks the group: the
+// dense layers of the O-Net have 4 096 rows only - 64 row tiles - and want more blocks than that); HIN x WIN input map of CIN
+// channels; output HO x WO
+// POOL2 (O-Net conv3: 3x3, 64 -> 64, 10x10 -> 8x8): the block's 64 rows are ONE crop's 8 x 8 conv map, tile t = image rows 2t and
+// 2t + 1, so the 2x2 / stride-2 max pool is a maximum over lanes li, li ^ 1, li ^ 8, li ^ 9 of one accumulator tile: no LDS pass
+template <int L, int KH, int N, int NB, int HIN, int WIN, int CIN, int HO, int WO, bool POOL2 = false>
 __global__ __launch_bounds__(256, 2) void ro_gemm_split_kernel(RgArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int MT = 64, K = KH * L, NKS = K / 32, NT = N / 64, P = HO * WO;
-    static_assert(L % 32 == 0 && N % 64 == 0, "run length and couts");
+    constexpr int MT = 64, K = KH * L, NKS = K / 32, NT = NB / 64, P = HO * WO;
+    static_assert(L % 32 == 0 && NB % 64 == 0 && N % NB == 0, "run length and couts");
+    static_assert(!POOL2 || (HO == 8 && WO == 8), "the fused pool wants one 8 x 8 map per block");
     __shared__ __attribute__((aligned(16))) char xs[2][2][MT * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
@@ -84,7 +89,8 @@ __global__ __launch_bounds__(256, 2) void ro_gemm_split_kernel(RgArgs a) {
         }
     };
     // ---- weight fragments of this wave's NT cout tiles
-    const unsigned char* wbase = a.w + ((size_t)(wave * NT) * 2 * 64 + lane) * 16;
+    const int ct0 = blockIdx.y * (NB / 16) + wave * NT;            // the wave's first cout tile
+    const unsigned char* wbase = a.w + ((size_t)ct0 * 2 * 64 + lane) * 16;
     auto ldw = [&](int ks, half8 (&wh)[NT], half8 (&wl)[NT]) {
         const unsigned char* p = wbase + (size_t)ks * (N / 16) * 2 * 1024;
 #pragma unroll
@@ -133,19 +139,28 @@ __global__ __launch_bounds__(256, 2) void ro_gemm_split_kernel(RgArgs a) {
     // ---- epilogue: lane = row t * 16 + li, couts (wave * NT + i) * 16 + 4 kq .. + 3
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        const int co = (wave * NT + i) * 16 + 4 * kq;
+        const int co = (ct0 + i) * 16 + 4 * kq;
         const float4v bb = *reinterpret_cast<const float4v*>(a.bias + co);
         float4v ss = {1.f, 1.f, 1.f, 1.f};
         if (a.slope) ss = *reinterpret_cast<const float4v*>(a.slope + co);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int m = row0 + t * 16 + li;
-            if (m < nrows) {
-                float4v v = acc[i][t] + bb;
-                if (a.slope) {
+            float4v v = acc[i][t] + bb;
+            if (a.slope) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * ss[e];
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * ss[e];
+            }
+            if constexpr (POOL2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float mx = fmaxf(v[e], __shfl_xor(v[e], 1, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+                    v[e] = mx;
                 }
+                if ((li & 9) == 0)          // the window's top-left lane: pooled pixel (t, (li & 7) >> 1) of slot blockIdx.x
+                    *reinterpret_cast<float4v*>(a.y + ((size_t)blockIdx.x * 16 + t * 4 + ((li & 7) >> 1)) * N + co) = v;
+            } else if (m < nrows) {
                 *reinterpret_cast<float4v*>(a.y + (size_t)m * N + co) = v;
             }
         }
@@ -153,10 +168,10 @@ __global__ __launch_bounds__(256, 2) void ro_gemm_split_kernel(RgArgs a) {
 #endif
 }
 
-template <int L, int KH, int N, int HIN, int WIN, int CIN, int HO, int WO>
+template <int L, int KH, int N, int NB, int HIN, int WIN, int CIN, int HO, int WO, bool POOL2 = false>
 int launch_rg(const RgArgs& a, hipStream_t s) {
     const int64_t nrows = (int64_t)a.nslots * HO * WO;
-    ro_gemm_split_kernel<L, KH, N, HIN, WIN, CIN, HO, WO><<<(unsigned)((nrows + 63) / 64), 256, 0, s>>>(a);
+    ro_gemm_split_kernel<L, KH, N, NB, HIN, WIN, CIN, HO, WO, POOL2><<<dim3((unsigned)((nrows + 63) / 64), N / NB), 256, 0, s>>>(a);
     return FR_OK;
 }
 
@@ -183,6 +198,7 @@ __global__ void ro_gemm_pack_kernel(const float* __restrict__ w, unsigned char* 
 extern "C" size_t fr_ro_gemm_weight_bytes(int layer) {
     switch (layer) {
         case 12: return (size_t)64 * 192 * 4;
+        case 22: return (size_t)64 * 576 * 4;
         case 13: return (size_t)128 * 576 * 4;
         case 23: return (size_t)128 * 256 * 4;
         case 24: return (size_t)256 * 1152 * 4;
@@ -195,10 +211,11 @@ extern "C" int fr_ro_gemm_pack(int layer, const float* w, void* out, fr_stream_t
     int N, K;
     switch (layer) {
         case 12: N = 64; K = 192; break;
+        case 22: N = 64; K = 576; break;
         case 13: N = 128; K = 576; break;
         case 23: N = 128; K = 256; break;
         case 24: N = 256; K = 1152; break;
-        default: FR_REQUIRE(false, "fr_ro_gemm_pack: layer must be 12, 13, 23 or 24 (got %d)", layer);
+        default: FR_REQUIRE(false, "fr_ro_gemm_pack: layer must be 12, 13, 22, 23 or 24 (got %d)", layer);
     }
     const int total = (K / 32) * (N / 16) * 2 * 64;
     ro_gemm_pack_kernel<<<(total + 255) / 256, 256, 0, fr_stream(stream)>>>(w, (unsigned char*)out, N, K);
@@ -213,12 +230,16 @@ extern "C" int fr_ro_gemm_split(int layer, const float* x, const void* w_packed,
     RgArgs a{x, (const unsigned char*)w_packed, bias, slope, y, counts, cap, nslots};
     hipStream_t s = fr_stream(stream);
     int rc;
-    switch (layer) {          //                  L   KH   N  HIN WIN CIN HO WO
-        case 12: rc = launch_rg<96, 2, 64, 4, 4, 48, 3, 3>(a, s); break;        // R-Net conv3: 2x2, 48 -> 64, 4x4 -> 3x3
-        case 13: rc = launch_rg<576, 1, 128, 3, 3, 64, 1, 1>(a, s); break;      // R-Net dense4: the 3x3x64 map -> 128
-        case 23: rc = launch_rg<128, 2, 128, 4, 4, 64, 3, 3>(a, s); break;      // O-Net conv4: 2x2, 64 -> 128
-        case 24: rc = launch_rg<1152, 1, 256, 3, 3, 128, 1, 1>(a, s); break;    // O-Net dense5: the 3x3x128 map -> 256
-        default: FR_REQUIRE(false, "fr_ro_gemm_split: layer must be 12, 13, 23 or 24 (got %d)", layer);
+    const bool few = (int64_t)nslots <= 16384;                 // few rows: cout groups of 64 per block, more blocks
+    switch (layer) {          //                  L   KH   N   NB HIN WIN CIN HO WO
+        case 12: rc = launch_rg<96, 2, 64, 64, 4, 4, 48, 3, 3>(a, s); break;        // R-Net conv3: 2x2, 48 -> 64, 4x4 -> 3x3
+        case 13: rc = few ? launch_rg<576, 1, 128, 64, 3, 3, 64, 1, 1>(a, s)       // R-Net dense4: the 3x3x64 map -> 128
+                          : launch_rg<576, 1, 128, 128, 3, 3, 64, 1, 1>(a, s); break;
+        case 22: rc = launch_rg<192, 3, 64, 64, 10, 10, 64, 8, 8, true>(a, s); break;   // O-Net conv3: 3x3, 64 -> 64, 10x10 -> 8x8, + 2x2 / s2 pool -> 4x4
+        case 23: rc = launch_rg<128, 2, 128, 128, 4, 4, 64, 3, 3>(a, s); break;     // O-Net conv4: 2x2, 64 -> 128
+        case 24: rc = few ? launch_rg<1152, 1, 256, 64, 3, 3, 128, 1, 1>(a, s)     // O-Net dense5: the 3x3x128 map -> 256
+                          : launch_rg<1152, 1, 256, 256, 3, 3, 128, 1, 1>(a, s); break;
+        default: FR_REQUIRE(false, "fr_ro_gemm_split: layer must be 12, 13, 22, 23 or 24 (got %d)", layer);
     }
     if (rc != FR_OK) return rc;
     FR_CHECK_LAUNCH("ro_gemm_split_kernel");

@@ -203,6 +203,7 @@ class MTCNNHIP:
         self._gemm = {}
         for lid, wconv, b, sl in ((12, r["conv3.weight"], r["conv3.bias"], r["prelu3.weight"]),
                                   (13, _dense_as_conv(r["dense4.weight"], 3, 64), r["dense4.bias"], r["prelu4.weight"]),
+                                  (22, o["conv3.weight"], o["conv3.bias"], o["prelu3.weight"]),
                                   (23, o["conv4.weight"], o["conv4.bias"], o["prelu4.weight"]),
                                   (24, _dense_as_conv(o["dense5.weight"], 3, 128), o["dense5.bias"], o["prelu5.weight"])):
             wk = wconv.permute(0, 2, 3, 1).reshape(wconv.shape[0], -1).to(torch.float32).contiguous().to(d)
@@ -406,11 +407,12 @@ class MTCNNHIP:
             x, h, w = self._dconv(x, self.o1, B, 48, 48, **k)   # + fused 3x3/s2 pool -> 23x23
         if x2 is None:
             x, h, w = self._dconv(x, self.o2, B, h, w, **k)     # + fused 3x3/s2 pool -> 10x10
-        x, h, w = self._dconv(x, self.o3, B, h, w, **k)     # + fused 2x2/s2 pool -> 4x4
         if x2 is not None and self.split_tail:
+            x = self._gemm_split(22, x, B, (4, 4, 64), counts, cap)     # conv3 + fused 2x2/s2 pool -> 4x4
             x = self._gemm_split(23, x, B, (3, 3, 128), counts, cap)
             x = self._gemm_split(24, x, B, (1, 1, 256), counts, cap)
         else:
+            x, h, w = self._dconv(x, self.o3, B, h, w, **k)     # + fused 2x2/s2 pool -> 4x4
             x, h, w = self._dconv(x, self.o4, B, h, w, **k)
             x, h, w = self._dconv(x, self.o5, B, h, w, **k)
         x, h, w = self._dconv(x, self.o6, B, 1, 1, **k)

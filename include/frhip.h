@@ -349,7 +349,8 @@ int fr_ro_conv2_split(int net, const void* x_split, const float* w, const float*
                       int nslots, const int32_t* counts, int cap, int32_t* zero_word, fr_stream_t stream);
 /* The small tail layers of R-Net / O-Net as one split-precision GEMM kernel on the f16 matrix cores (x = hi + lo in f16,
  * three MFMAs per product term, f32 accumulate; ~1e-6 of the output's scale from the f32 layers): layer 12 = R-Net conv3
- * (2x2, 48 -> 64, [.,4,4,48] -> [.,3,3,64]), 13 = R-Net dense4 ([.,3,3,64] -> [.,128]), 23 = O-Net conv4 (2x2, 64 -> 128,
+ * (2x2, 48 -> 64, [.,4,4,48] -> [.,3,3,64]), 13 = R-Net dense4 ([.,3,3,64] -> [.,128]), 22 = O-Net conv3 (3x3, 64 -> 64,
+ * [.,10,10,64] -> 8x8 -> 2x2/s2 max pool -> [.,4,4,64]), 23 = O-Net conv4 (2x2, 64 -> 128,
  * [.,4,4,64] -> [.,3,3,128]), 24 = O-Net dense5 ([.,3,3,128] -> [.,256]) - the layers of the same ids of fr_dconv_mfma_f32,
  * + bias + PReLU.  w_packed: fr_ro_gemm_pack(layer, w) of the f32 weights [Cout][K], K = (kh, kw, channel) ascending
  * (fr_ro_gemm_weight_bytes(layer) bytes).  counts / cap as fr_dconv_mfma_f32.  Batch path only: see fr_ro_conv2_split. */

@@ -677,6 +677,7 @@ def test_split_gemm_tail_layers_vs_f32_layers():
     valid = (torch.arange(cap, device="cuda")[None, :] < counts[:, None]).reshape(-1)
     B = N * cap
     for lid, layer, shape_in, shape_out in ((12, d.r3, (4, 4, 48), (3, 3, 64)), (13, d.r4, (3, 3, 64), (1, 1, 128)),
+                                            (22, d.o3, (10, 10, 64), (4, 4, 64)),      # conv3 + the fused 2x2/s2 pool
                                             (23, d.o4, (4, 4, 64), (3, 3, 128)), (24, d.o5, (3, 3, 128), (1, 1, 256))):
         x = torch.randn((B, *shape_in), generator=g, device="cuda") * 1.5
         want, _, _ = d._dconv(x, layer, B, shape_in[0], shape_in[1], counts=counts, cap=cap)
