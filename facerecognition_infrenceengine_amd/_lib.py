@@ -114,7 +114,7 @@ SIGNATURES = {
     "fr_dconv_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "fr_dconv_mfma_f32": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P]),
     "fr_crop_conv1_f32": (_I, [_I, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P]),
-    "fr_crop_conv1_split": (_I, [_I, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "fr_crop_conv1_split": (_I, [_I, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
     "fr_crop_conv1_list_f32": (_I, [_I, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P]),
     "fr_ro_conv2_split": (_I, [_I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     "fr_ro_gemm_weight_bytes": (_Z, [_I]),

@@ -68,7 +68,13 @@ __device__ __forceinline__ float vmax_r(float x, float y) {        // no canonic
 // S: crop size; NG: cout quads (COUT = 4 NG real channels written); PB: pooled rows per band (a band = 2 PB + 1 conv rows);
 // RPB: consecutive crop slots per block.  The source bytes of the NEXT valid slot's crop are fetched (raw, into
 // registers) before the current slot's conv and blended into LDS after it, so the frame gather's latency is covered.
-template <int S, int NG, int COUT, int PB, int RPB, bool SPLIT = false, bool LIST = false>
+// F16 (with SPLIT, the batch path): the conv runs on the f16 matrix cores with split-precision operands instead of the 4x4x1 f32
+// form.  The resized crop is kept as hi | lo f16 planes of 4-channel pixels (8 B: R, G, B, 0), so the (kw = 0..3, channel 0..3)
+// values of one kernel row are 32 contiguous bytes and K = (kh, kw', c') = 4 x 4 x 4 with zero weights at kh = 3, kw' = 3,
+// c' = 3: two K = 32 steps, a B fragment = 16 B (2 pixels) at an 8-byte aligned address.  6 MFMAs of 16 cycles per 16 pixels x
+// 16 couts against 27 x 4 = 108 4x4x1 MFMAs of 8 cycles per 64 pixels x 16 couts: ~2.8x fewer matrix cycles, and the work
+// splits in tiles of 16 pixels instead of units of 64.  ~1e-6 from the f32 form (the exact pass covers the threshold).
+template <int S, int NG, int COUT, int PB, int RPB, bool SPLIT = false, bool LIST = false, bool F16 = false>
 __global__ __launch_bounds__(256) void crop_conv1_kernel(RoArgs a) {
     constexpr int C = S - 2;                                     // conv map size
     constexpr int P = (C - 3 + 1) / 2 + 1;                       // ceil((C - 3) / 2) + 1 pooled size (ceil mode)
@@ -80,9 +86,11 @@ __global__ __launch_bounds__(256) void crop_conv1_kernel(RoArgs a) {
     constexpr int NPF = (S * S + 255) / 256;                     // crop pixels per thread
     static_assert(NG * 4 <= 32 && COUT <= NG * 4, "cout quads");
     constexpr int NW = (27 * NG + 15) / 16;                      // weight registers
+    constexpr int XPX = S * S + S + 8;                           // F16: pixels per plane incl. the zero slack behind the image (kh = 3, kw' = 3 read there)
+    constexpr int XFLOATS = F16 ? (2 * XPX * 8 / 4 + 3) & ~3 : (S * S * 3 + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) float lds_ro[];
-    float* xin = lds_ro;                                         // [S*S][3]
-    int4v* tab = reinterpret_cast<int4v*>(lds_ro + ((S * S * 3 + 3) & ~3));          // [2][2 S] lerp tables (double-buffered)
+    float* xin = lds_ro;                                         // [S*S][3] f32, or F16: hi | lo planes of [XPX][4] f16
+    int4v* tab = reinterpret_cast<int4v*>(lds_ro + XFLOATS);     // [2][2 S] lerp tables (double-buffered)
     float4* sbox_mem = reinterpret_cast<float4*>(tab + 4 * S);  // [RPB] the block's boxes (one global read, off the per-slot path)
     int* sorig = reinterpret_cast<int*>(sbox_mem + RPB);         // [RPB] the slots' numbers in the cascade's slot space (LIST: list[s])
     float* ot = reinterpret_cast<float*>(sorig + ((RPB + 3) & ~3));      // [BR * C][CS] conv tile
@@ -108,11 +116,30 @@ __global__ __launch_bounds__(256) void crop_conv1_kernel(RoArgs a) {
     }
     __syncthreads();
     // ---- weights: slot c = k * NG + g -> lanes 4 (c % 16) + r of register c / 16 hold W[k][4g + r]
-    float wreg[NW];
+    float wreg[F16 ? 1 : NW];
+    half8 wfh[F16 ? 2 : 1][2], wfl[F16 ? 2 : 1][2];              // F16: A fragments [K step][cout tile]: row = cout li, k = 8 kq + j
+    if constexpr (F16) {
+        unsigned char* xz = reinterpret_cast<unsigned char*>(xin);
+        for (int e = tid; e < (S + 8) * 2; e += 256)            // the slack pixels of both planes: zero, once
+            *reinterpret_cast<unsigned long long*>(xz + ((e & 1) * XPX + S * S + (e >> 1)) * 8) = 0ull;
+        const int li_ = lane & 15, kq_ = lane >> 4;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int kh = 2 * st + (kq_ >> 1), kw = (kq_ & 1) * 2 + (j >> 2), c = j & 3, co = ct * 16 + li_;
+                    const float w = (kh < 3 && kw < 3 && c < 3 && co < NG * 4) ? a.w[((kh * 3 + kw) * 3 + c) * (NG * 4) + co] : 0.f;
+                    const half_t h = (half_t)w;
+                    wfh[st][ct][j] = h; wfl[st][ct][j] = (half_t)(w - (float)h);
+                }
+    } else {
 #pragma unroll
     for (int v = 0; v < NW; ++v) {
         const int c = v * 16 + (lane >> 2), r = lane & 3;
         wreg[v] = c < 27 * NG ? a.w[(c / NG) * (NG * 4) + (c % NG) * 4 + r] : 0.f;
+    }
     }
     bool mono = true;
     for (int c = 0; c < NG * 4; ++c) mono = mono && a.slope[c] >= 0.f;
@@ -207,7 +234,20 @@ __global__ __launch_bounds__(256) void crop_conv1_kernel(RoArgs a) {
                     v[ch] = __builtin_fmaf(bilerp_r(p00, p01, p10, p11, wx, wy), 0.0078125f, -0.99609375f);      // == (s - 127.5) * 2^-7 bit for bit (pnet_conv1.hip)
                 }
             }
-            xin[t * 3 + 0] = v[0]; xin[t * 3 + 1] = v[1]; xin[t * 3 + 2] = v[2];
+            if constexpr (F16) {
+                half4 hi, lo;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const half_t h = (half_t)v[ch];
+                    hi[ch] = h; lo[ch] = (half_t)(v[ch] - (float)h);
+                }
+                hi[3] = lo[3] = (half_t)0.f;
+                unsigned char* xz = reinterpret_cast<unsigned char*>(xin);
+                *reinterpret_cast<half4*>(xz + t * 8) = hi;
+                *reinterpret_cast<half4*>(xz + (XPX + t) * 8) = lo;
+            } else {
+                xin[t * 3 + 0] = v[0]; xin[t * 3 + 1] = v[1]; xin[t * 3 + 2] = v[2];
+            }
         }
     };
 
@@ -227,6 +267,48 @@ __global__ __launch_bounds__(256) void crop_conv1_kernel(RoArgs a) {
         const int r0 = band * 2 * PB;                                         // first conv row of the band
         const int nrow = min(BR, C - r0);
         const int npx = nrow * C;
+        if constexpr (F16) {
+            // ---- conv on the f16 matrix cores: tiles of 16 flattened conv pixels, one per wave at a time
+            typedef half8 half8_a8 __attribute__((aligned(8)));
+            const unsigned char* xz = reinterpret_cast<const unsigned char*>(xin);
+            const int li_ = lane & 15, kq_ = lane >> 4;
+            for (int tl = wave; tl * 16 < npx; tl += 4) {
+                const int pidx = min(tl * 16 + li_, npx - 1);
+                const int ly = pidx / C, lx = pidx - ly * C;
+                const unsigned char* pb = xz + ((r0 + ly + (kq_ >> 1)) * S + lx + 2 * (kq_ & 1)) * 8;
+                const half8 h0 = *reinterpret_cast<const half8_a8*>(pb), l0 = *reinterpret_cast<const half8_a8*>(pb + XPX * 8);
+                const half8 h1 = *reinterpret_cast<const half8_a8*>(pb + 2 * S * 8), l1 = *reinterpret_cast<const half8_a8*>(pb + (XPX + 2 * S) * 8);
+                float4v acc[2];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    float4v d = {0.f, 0.f, 0.f, 0.f};
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfl[0][ct], h0, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[0][ct], l0, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfl[1][ct], h1, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[1][ct], l1, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[0][ct], h0, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[1][ct], h1, d, 0, 0, 0);
+                    acc[ct] = d;
+                }
+                if (tl * 16 + li_ < npx) {
+                    float* o = ot + (tl * 16 + li_) * CS;
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        const int co = ct * 16 + 4 * kq_;        // the lane's 4 couts of this tile
+                        if (co < NG * 4) {
+                            float4v v = acc[ct];
+                            if (!mono) {
+                                v += *reinterpret_cast<const float4v*>(a.bias + co);
+                                const float4v sv = *reinterpret_cast<const float4v*>(a.slope + co);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * sv[e];
+                            }
+                            *reinterpret_cast<float4v*>(o + co) = v;
+                        }
+                    }
+                }
+            }
+        } else
         // ---- conv: units of 64 flattened conv pixels, one unit per wave at a time
         for (int u = wave; u * 64 < npx; u += 4) {
             const int pidx = min(u * 64 + lane, npx - 1);                    // lanes past the band: any valid pixel, not stored
@@ -318,13 +400,14 @@ __global__ __launch_bounds__(256) void crop_conv1_kernel(RoArgs a) {
     }
 }
 
-template <int S, int NG, int COUT, int PB, int RPB, bool SPLIT = false, bool LIST = false>
+template <int S, int NG, int COUT, int PB, int RPB, bool SPLIT = false, bool LIST = false, bool F16 = false>
 int launch_ro(const RoArgs& a, int nslots, hipStream_t s) {
     constexpr int C = S - 2;
     constexpr int rows = 2 * PB + 1 < C ? 2 * PB + 1 : C;
     constexpr int CS = (NG * 4) % 32 ? NG * 4 : NG * 4 + 4;
-    const size_t lds = (size_t)(((S * S * 3 + 3) & ~3) + 4 * S * 4 + RPB * 4 + ((RPB + 3) & ~3) + rows * C * CS) * sizeof(float);
-    auto kern = crop_conv1_kernel<S, NG, COUT, PB, RPB, SPLIT, LIST>;
+    constexpr int XFLOATS = F16 ? (2 * (S * S + S + 8) * 8 / 4 + 3) & ~3 : (S * S * 3 + 3) & ~3;
+    const size_t lds = (size_t)(XFLOATS + 4 * S * 4 + RPB * 4 + ((RPB + 3) & ~3) + rows * C * CS) * sizeof(float);
+    auto kern = crop_conv1_kernel<S, NG, COUT, PB, RPB, SPLIT, LIST, F16>;
     if (lds > 64 * 1024) {
         static FrDevLatch latch;
         if (!fr_raise_lds(reinterpret_cast<const void*>(kern), lds, latch)) {
@@ -364,7 +447,7 @@ extern "C" int fr_crop_conv1_f32(int net, const uint8_t* frames, int nframes, in
 // the input format of fr_ro_conv2_split.  Same arithmetic up to the split, which is exact to 22 mantissa bits.
 extern "C" int fr_crop_conv1_split(int net, const uint8_t* frames, int nframes, int H, int W, const float* boxes,
                                    const int32_t* counts, int cap, const float* w, const float* bias, const float* slope,
-                                   void* y_split, fr_stream_t stream) {
+                                   void* y_split, int conv_f16, fr_stream_t stream) {
     FR_REQUIRE(frames && boxes && counts && w && bias && slope && y_split, "fr_crop_conv1_split: null pointer");
     FR_REQUIRE(nframes > 0 && cap > 0 && H > 0 && W > 0 && (int64_t)H * W * 3 < (1ll << 31) && (int64_t)H * W * 3 >= 8,
                "fr_crop_conv1_split: bad frame size");
@@ -373,6 +456,11 @@ extern "C" int fr_crop_conv1_split(int net, const uint8_t* frames, int nframes, 
     hipStream_t s = fr_stream(stream);
     const int64_t nslots = (int64_t)nframes * cap;
     int rc;
+    if (conv_f16) {       // the conv itself on the f16 matrix cores (split precision)
+        if (net == 0) rc = cap % 8 == 0 && nslots >= 8192 ? launch_ro<24, 7, 28, 4, 8, true, false, true>(a, nframes * cap, s) : launch_ro<24, 7, 28, 4, 1, true, false, true>(a, nframes * cap, s);
+        else if (net == 1) rc = cap % 4 == 0 && nslots >= 2048 ? launch_ro<48, 8, 32, 2, 4, true, false, true>(a, nframes * cap, s) : launch_ro<48, 8, 32, 2, 1, true, false, true>(a, nframes * cap, s);
+        else { FR_REQUIRE(false, "fr_crop_conv1_split: net must be 0 (R-Net) or 1 (O-Net)"); }
+    } else
     if (net == 0) rc = cap % 8 == 0 && nslots >= 8192 ? launch_ro<24, 7, 28, 4, 8, true>(a, nframes * cap, s) : launch_ro<24, 7, 28, 4, 1, true>(a, nframes * cap, s);
     else if (net == 1) rc = cap % 4 == 0 && nslots >= 2048 ? launch_ro<48, 8, 32, 2, 4, true>(a, nframes * cap, s) : launch_ro<48, 8, 32, 2, 1, true>(a, nframes * cap, s);
     else { FR_REQUIRE(false, "fr_crop_conv1_split: net must be 0 (R-Net) or 1 (O-Net)"); }

@@ -177,6 +177,7 @@ class MTCNNHIP:
         # weights as [cout][tap][32 channels] f32; the crops whose logit lies within ``ro_margin`` of the stage threshold are
         # re-evaluated by the all-f32 layers, so every keep / reject decision is that of f32 arithmetic
         self.split_ro = True
+        self.split_conv1 = True             # with split_ro: the first layer's conv on the f16 matrix cores too (csrc/ro_conv1.hip, F16)
         self.split_tail = True              # with split_ro: conv3 / dense4 (R-Net), conv4 / dense5 (O-Net) as split-precision GEMMs too
         self.ro_margin = 1e-3               # in logit units; the split path's measured head error is ~1e-6
         self.ro_list_cap = (1024, 256)      # slots of the exact pass's work list (R-Net, O-Net); entries past it keep the split values
@@ -350,7 +351,7 @@ class MTCNNHIP:
         p1, p2, c2 = (11, 4, 48) if net == 0 else (23, 10, 64)
         xs = self._new((N * cap, p1 * p1, 128), torch.uint8)
         self.lib.fr_crop_conv1_split(net, self._fptr(frames), N, H, W, _lib.ptr(boxes), _lib.ptr(counts), cap, _lib.ptr(w1),
-                                     _lib.ptr(b1), _lib.ptr(s1), _lib.ptr(xs), self._s)
+                                     _lib.ptr(b1), _lib.ptr(s1), _lib.ptr(xs), 1 if self.split_conv1 else 0, self._s)
         y = self._f32(N * cap, p2, p2, c2)
         lc = self._i32(1)                   # the exact pass's list counter: cleared by the conv2 kernel, filled by fr_ro_margin_list
         self.lib.fr_ro_conv2_split(net, _lib.ptr(xs), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(s2), _lib.ptr(y), N * cap,

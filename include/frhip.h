@@ -329,10 +329,12 @@ int fr_crop_conv1_f32(int net, const uint8_t* frames, int nframes, int H, int W,
                       float* y, fr_stream_t stream);
 /* The same layer with its pooled map written as SPLIT f16 (x = hi + lo, hi = f16(x), lo = f16(x - hi)):
  * y_split [nframes*cap][P*P pixels][hi 32 channels | lo 32 channels], 128 B per pixel, channels >= Cout zero (P = 11 / 23) -
- * the operand format of fr_ro_conv2_split.  Same slots computed / left unwritten as fr_crop_conv1_f32. */
+ * the operand format of fr_ro_conv2_split.  Same slots computed / left unwritten as fr_crop_conv1_f32.
+ * conv_f16 = 0: the conv itself is the f32 form's (the map is hi + lo of fr_crop_conv1_f32's to 2^-21); 1: the conv runs on
+ * the f16 matrix cores with split-precision operands too (~1e-6 of the map's scale from the f32 form). */
 int fr_crop_conv1_split(int net, const uint8_t* frames, int nframes, int H, int W, const float* boxes,
                         const int32_t* counts, int cap, const float* w, const float* bias, const float* slope,
-                        void* y_split, fr_stream_t stream);
+                        void* y_split, int conv_f16, fr_stream_t stream);
 /* fr_crop_conv1_f32 for a compact LIST of slots: row i of y is the f32 map of slot list[i], i < min(*list_count, list_cap)
  * (device-side count; boxes / frames are indexed by list[i], frame = list[i] / cap). */
 int fr_crop_conv1_list_f32(int net, const uint8_t* frames, int nframes, int H, int W, const float* boxes, int cap,

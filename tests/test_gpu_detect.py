@@ -513,9 +513,24 @@ def test_split_f16_conv2_layers_vs_f32_layers(negative_slopes):
         w1, b1, s1 = d._rc1 if net == 0 else d._oc1
         xs = torch.full((N * cap, p1 * p1, 128), 0x7f, dtype=torch.uint8, device="cuda")
         lib.fr_crop_conv1_split(net, _lib.ptr(frames), N, H, W, _lib.ptr(boxes), _lib.ptr(counts), cap, _lib.ptr(w1), _lib.ptr(b1),
-                                _lib.ptr(s1), _lib.ptr(xs), _lib.stream_ptr())
+                                _lib.ptr(s1), _lib.ptr(xs), 0, _lib.stream_ptr())
+        d.split_conv1 = False
         got, _ = d.crop_conv12_split(net, frames, boxes, counts, cap)
+        # ... and with the first layer's conv on the f16 matrix cores too (the product setting)
+        xs16 = torch.full((N * cap, p1 * p1, 128), 0x7f, dtype=torch.uint8, device="cuda")
+        lib.fr_crop_conv1_split(net, _lib.ptr(frames), N, H, W, _lib.ptr(boxes), _lib.ptr(counts), cap, _lib.ptr(w1), _lib.ptr(b1),
+                                _lib.ptr(s1), _lib.ptr(xs16), 1, _lib.stream_ptr())
+        d.split_conv1 = True
+        got16, _ = d.crop_conv12_split(net, frames, boxes, counts, cap)
         torch.cuda.synchronize()
+        hl16 = xs16.view(torch.float16).reshape(N * cap, p1, p1, 2, 32).float()
+        m16 = (hl16[..., 0, :] + hl16[..., 1, :])[valid][..., :c1]
+        e1 = float((m16 - m1[valid]).abs().max())
+        assert e1 <= 4e-6 * float(m1[valid].abs().max()), (net, e1)                  # the f16-matrix-core conv1 map
+        assert float(hl16[valid][..., c1:].abs().max() if c1 < 32 else 0.0) == 0.0
+        e2 = float((got16[valid] - want[valid]).abs().max())
+        print(f"\nnet {net}: conv1 on the f16 matrix cores: map max |d| {e1:.3e}; conv2 map behind it max |d| {e2:.3e}")
+        assert e2 <= 1.5e-5 * float(want[valid].abs().max()), (net, e2)
         hl = xs.view(torch.float16).reshape(N * cap, p1, p1, 2, 32).float()
         hi, lo = hl[..., 0, :], hl[..., 1, :]
         assert torch.equal(hi[valid][..., :c1], m1[valid].half().float())             # hi = f16(x)

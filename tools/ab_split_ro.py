@@ -10,8 +10,8 @@ app = FaceAnalysis(name="synthetic", arch="r100", cap_o=4).prepare(ctx_id=0)
 frames = bench.synth_frames(64, 1080, 1920, 0, torch.device("cuda:0"))
 app.det.refined_cells = torch.zeros(1, dtype=torch.int32, device="cuda")
 for rep in range(2):
-    for split, band, tail in ((False, False, False), (True, False, False), (True, True, False), (True, True, True)):
-        app.det.split_ro, app.det.pnet_band, app.det.split_tail = split, band, tail
+    for split, band, tail, c1 in ((False, False, False, False), (True, True, False, False), (True, True, True, False), (True, True, True, True)):
+        app.det.split_ro, app.det.pnet_band, app.det.split_tail, app.det.split_conv1 = split, band, tail, c1
         for _ in range(3):
             app.det.detect_batch(frames)
         torch.cuda.synchronize()
@@ -33,5 +33,5 @@ for rep in range(2):
         extra = " P-Net cells re-evaluated per batch: %d" % (int(app.det.refined_cells[0]) // 10)
         if split:
             extra += "; exact-pass crops (R, O): %s" % [int(app.det._ro_lists[k][0]) for k in (0, 1)]
-        print("split_ro", split, "pnet_band", band, "split_tail", tail, "detect ms %.3f" % (e0.elapsed_time(e1) / 10), {k: round(v, 3) for k, v in acc.items()},
+        print("split_ro", split, "pnet_band", band, "split_tail", tail, "split_conv1", c1, "detect ms %.3f" % (e0.elapsed_time(e1) / 10), {k: round(v, 3) for k, v in acc.items()},
               "faces", int(out[3].sum()), extra, flush=True)
