@@ -18,6 +18,13 @@
 #include "common.h"
 #include <type_traits>
 
+#ifndef RC1_PB_R           // developer A/B (tools/abl_rc1.py): pooled rows per band / slots per block of the batch path's F16 form
+#define RC1_PB_R 3         // measured (64 x 512 random boxes, us): PB x RPB 4x8 495, 3x8 417, 2x8 434, 4x16 429, 3x16 397, 3x32 see tools/abl_rc1.py
+#define RC1_RPB_R 16
+#define RC1_PB_O 2         // O-Net (64 x 64 boxes): 2x4 281, 2x8 279, 1x4 317, 3x4 446, 2x2 288
+#define RC1_RPB_O 4
+#endif
+
 namespace {
 
 template <int N, int I = 0, class F>
@@ -457,8 +464,8 @@ extern "C" int fr_crop_conv1_split(int net, const uint8_t* frames, int nframes, 
     const int64_t nslots = (int64_t)nframes * cap;
     int rc;
     if (conv_f16) {       // the conv itself on the f16 matrix cores (split precision)
-        if (net == 0) rc = cap % 8 == 0 && nslots >= 8192 ? launch_ro<24, 7, 28, 4, 8, true, false, true>(a, nframes * cap, s) : launch_ro<24, 7, 28, 4, 1, true, false, true>(a, nframes * cap, s);
-        else if (net == 1) rc = cap % 4 == 0 && nslots >= 2048 ? launch_ro<48, 8, 32, 2, 4, true, false, true>(a, nframes * cap, s) : launch_ro<48, 8, 32, 2, 1, true, false, true>(a, nframes * cap, s);
+        if (net == 0) rc = cap % RC1_RPB_R == 0 && nslots >= 8192 ? launch_ro<24, 7, 28, RC1_PB_R, RC1_RPB_R, true, false, true>(a, nframes * cap, s) : launch_ro<24, 7, 28, 4, 1, true, false, true>(a, nframes * cap, s);
+        else if (net == 1) rc = cap % RC1_RPB_O == 0 && nslots >= 2048 ? launch_ro<48, 8, 32, RC1_PB_O, RC1_RPB_O, true, false, true>(a, nframes * cap, s) : launch_ro<48, 8, 32, 2, 1, true, false, true>(a, nframes * cap, s);
         else { FR_REQUIRE(false, "fr_crop_conv1_split: net must be 0 (R-Net) or 1 (O-Net)"); }
     } else
     if (net == 0) rc = cap % 8 == 0 && nslots >= 8192 ? launch_ro<24, 7, 28, 4, 8, true>(a, nframes * cap, s) : launch_ro<24, 7, 28, 4, 1, true>(a, nframes * cap, s);
