@@ -217,7 +217,12 @@ def main():
                          "re-rank of the top 4 / 8")
     ap.add_argument("--force-exchange", action="store_true",
                     help="with one rank: still run the two all-gathers of the sharded match over RCCL (rehearsal)")
-    ap.add_argument("--pipes", type=int, default=2, help="independent (detector, embedder) stream pairs, used round-robin")
+    ap.add_argument("--pipes", type=int, default=0,
+                    help="independent (detector, embedder) stream pairs, used round-robin.  Default: 1 for the 64-frame batches, 2 for "
+                         "C3's 8 x 4K.  Measured with round 4's detector (tools/ab_bench_knobs.sh, same box, pipes x detector level "
+                         "streams): C2 2x1 23 400 faces/s, 1x1 24 150, 1x2 25 400, 2x2 24 000; C5 25 500 / 25 470 / 27 070 / 25 060; "
+                         "C3 20 780 / 18 800 / 18 340 / 20 880 - with one pair the one-workgroup-per-CU stage kernels of step i find the "
+                         "CUs free of step i + 2's detector blocks")
     ap.add_argument("--prio", default="none", choices=["none", "det", "emb"], help="stream given high priority")
     ap.add_argument("--one-stream", action="store_true", help="detector and embedder on one stream (no overlap)")
     ap.add_argument("--det-sides", type=int, default=None, help="A/B: side streams the detector deals pyramid levels 1.. over")
@@ -329,6 +334,8 @@ def main():
         app.det.level_streams = args.det_sides
     if args.det_level_nms is not None:
         app.det.merged_level_nms = args.det_level_nms == "merged"
+    if args.pipes <= 0:
+        args.pipes = 1 if FRAMES >= 16 else 2
     pipes = []
     for _ in range(args.pipes if two else 1):
         pipes.append((torch.cuda.Stream(device=device, priority=-1 if args.prio == "det" else 0) if two else None,

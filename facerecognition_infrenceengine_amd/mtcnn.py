@@ -137,7 +137,7 @@ class MTCNNHIP:
         self._sides = {}
         self._tls = threading.local()      # per-thread launch stream: detect_batch is re-entrant across threads
         self.one_stream = False            # True (profiling): every pyramid level on the caller's stream, per-kernel times add up
-        self.level_streams = 1             # side streams the pyramid levels 1.. are dealt over (detect_batch's default)
+        self.level_streams = 2             # side streams the pyramid levels 1.. are dealt over (detect_batch's default; round 4: 2 - see detect_batch)
         self.single_frame_level_streams = self.SINGLE_FRAME_LEVEL_STREAMS      # the same for batches of < 8 frames (0: as level_streams)
         self.phase_marks = None            # tools: a list -> (name, event on the caller's stream) at the cascade's phase ends
         self.merged_level_nms = True       # the per-level NMS of ALL levels as one launch behind the pyramid (False: one per level)
@@ -430,7 +430,9 @@ class MTCNNHIP:
         """frames: uint8 [N,H,W,3] BGR device tensor (contiguous).
 
         level_streams: side HIP streams (1 or 2) the pyramid levels 1.. are dealt over; level 0 stays on the caller's
-        stream.  Default ``self.level_streams`` = 1.  Measured (round 3): a 64 x 1080p batch ALONE (tools/bench_det_phases.py):
+        stream.  Default ``self.level_streams`` = 2 since round 4 (split-precision R-/O-Net, band-only exact P-Net pass: a 64 x 1080p
+        batch alone 5.30 ms with one side stream, 4.9 - 5.1 with two; inside the bench C2 24 150 -> 25 400 faces/s, C5 25 470 -> 27 070, C3
+        20 780 -> 20 880: tools/ab_bench_knobs.sh).  Round 3 had measured: a 64 x 1080p batch ALONE (tools/bench_det_phases.py):
         one side stream + an NMS launch per level 6.80 ms, two side streams 6.47, one launch for the NMS of all levels
         (``merged_level_nms``, the default: 768 one-workgroup sorts at once instead of twelve launches of 64) 6.54 / 6.37 ms.
         Inside the bench, where the detector shares the GPU with the embedder: 64 x 1080p the four combinations are within
