@@ -38,7 +38,7 @@ GALLERY_ROWS = 10_000
 FACES_PER_FRAME = 4                    # O-Net cap (C2 keeps F = 4 -> 256 faces/batch)
 MFMA_PEAK_TFLOPS = 2500.0              # dense f16/bf16 (MI355X_MICROARCH.md)
 MFMA_PEAK_TFLOPS_F8 = 5000.0           # dense fp8 (block-scaled MFMA with unit scales)
-PMC_FILE = "profiles/r03_pmc_traffic.json"
+PMC_FILE = "profiles/r04_pmc_traffic.json"
 
 
 def synth_frames(n, h, w, seed, device):
@@ -551,7 +551,7 @@ def main():
             for k in range(ing.depth):
                 ing.host_buffer(k)[...] = batches[k % nbatch].cpu().numpy()
             n_p = max(6, min(args.steps, 40))            # as many steps as the headline loop: the pipeline fill is a fixed cost
-            dt_p, faces_p, _, _ = run_loop(ing, n_p, 2)
+            dt_p, faces_p, _, _ = run_loop(ing, n_p, 4)
             side["value_pcie"] = round(faces_p / dt_p, 1)
             side["value_pcie_note"] = (f"{n_p} steps, frames uploaded from pinned host memory on a copy stream every step, each upload issued "
                                        f"{args.ingest_ahead} steps ahead of its step")
