@@ -29,7 +29,7 @@
 // at chunk c ^ (((X + KC Y + GK g) >> 1) & 3) with KC = W_out mod 8, GK = pixels per crop mod 8.  Then the key of the pixel a
 // lane reads for output pixel q and tap (kh, kw) is (((q + kw + KC kh) & 7) >> 1) - and q = 16 t + lane & 15, so it is ONE
 // value per (lane, tap), whatever the tile: a fragment address is (per-tile pixel base) + (per-tap chunk term) + immediate.
-// Brute-forced over the real tiles: every ds_read_b128 is conflict-free (R-Net: but for the tiles that straddle two
+// Brute-forced over the real tiles (tools/lds_swizzle_search.py): every ds_read_b128 is conflict-free (R-Net: but for the tiles that straddle two
 // crops), where plain or padded rows cost 1.7 - 1.9x the LDS cycles.
 // The conv map goes through an LDS tile (aliasing the item's own input buffer; O-Net: 32 couts at a time) to the pool;
 // pool-before-activation when every PReLU slope is >= 0 (the same bits, a ninth of the bias / PReLU work), as in the other
