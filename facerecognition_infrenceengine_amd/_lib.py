@@ -125,6 +125,9 @@ SIGNATURES = {
     "fr_pnet23_workspace_bytes": (_Z, [_I, _I, _I]),
     "fr_pnet23_split_f16": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _Z, _P]),
     "fr_maxpool_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fr_pnet_conv1_band": (_I, [_I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "fr_pnet_band_tiles_count": (_Z, [_I, _I, _I]),
+    "fr_pnet_band_tiles": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "fr_pnet_finish_levels": (_I, [C.POINTER(PnetLevel), _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _F, _P, _P]),
     "fr_pnet_candidates": (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P]),
     "fr_sort_nms": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P, _P, _I, _P]),

@@ -39,6 +39,7 @@ struct P1Args {
     float* y;                                  // pooled map f32 [B,Hp,Wp,12]
     unsigned char* y_split;                    // optional split-f16 copy, 64 B per pixel (pnet_fused.hip)
     int Ho, Wo, Hp, Wp, regions_x, regions_y;
+    const int32_t* list; const int32_t* list_count; int list_cap;     // LIST: the tiles to compute (numbers in the full launch's tile order)
 };
 
 typedef unsigned long long u64_unaligned __attribute__((aligned(1)));
@@ -82,17 +83,39 @@ __device__ __forceinline__ float vmax(float x, float y) {
 // Lerp tables of a tile: the source rows / columns and weights of its (rows + 2) level rows and 66 level columns are
 // computed ONCE per tile by 84 threads (not once per pixel by everybody) and read back from LDS.
 //   row entry {i0 * FW * 3, i1 * FW * 3, wy, valid}    column entry {x0 * 3, wx, x1 != x0, valid}
-template <int RPW, int RPB>
+// F16 (round 4, the batch path's band mode): the conv runs on the f16 matrix cores with split-precision operands (x = hi + lo in
+// f16, three MFMAs per product, f32 accumulate) and only the split map is written.  The level tile is kept as hi | lo planes of
+// 4-channel pixels (8 B: R, G, B, 0) so that the (kw' = 0..3, c' = 0..3) values of a kernel row are 32 contiguous bytes and
+// K = (kh, kw', c') = 4 x 4 x 4 with zero weights at kh = 3, kw' = 3, c' = 3 (the packing of ro_conv1.hip's F16 form): two K = 32
+// steps per 16 pixels x 16 couts, 6 MFMAs of 16 cycles, against 81 4x4x1 MFMAs of 8 cycles per 64 pixels - 2.6x fewer matrix
+// cycles, and a 4x4x1 MFMA holds the SIMD's vector issue for its whole 8 cycles.  The map differs from the f32 form's by ~1e-6; the
+// cells whose decision that could touch are re-evaluated from an EXACT map: the f32 form below, run over the tiles such a cell's
+// window touches (LIST: tile numbers from fr_pnet_band_tiles).
+template <int RPW, int RPB, bool F16 = false, bool LIST = false>
 __global__ __launch_bounds__(256, RPW == 4 ? 3 : 6) void pnet_conv1_kernel(P1Args a) {
     constexpr int TH = 4 * RPW, IH = TH + 2, NPX = IH * P1_IW;
     constexpr int NPF = (NPX + 255) / 256;
     constexpr int NTAB = IH + P1_IW;
-    __shared__ float xin[NPF * 256 * 3];      // slots past NPX (the last slot of some threads) land in the padding
+    constexpr int XPX = NPF * 256;            // pixel slots of the LDS tile; F16: per plane (the slack behind NPX is what kh = 3 / kw' = 3 read)
+    static_assert(!F16 || XPX >= NPX + P1_IW + 4, "slack behind the tile for the zero-weight taps");
+    __shared__ __attribute__((aligned(16))) float xin[F16 ? XPX * 4 : XPX * 3];      // slots past NPX (the last slot of some threads) land in the padding
     __shared__ __attribute__((aligned(16))) int4v tab[2][NTAB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // ---- weights: slot c = 3k + g (k = tap * 3 + channel) -> lanes 4 (c % 16) + r of register c / 16 hold W[k][4g + r]
     float wreg[6];
+    half8 wfh[2], wfl[2];                     // F16: A fragments of the two K steps: row = cout lane & 15, k = 8 (lane >> 4) + j
+    if constexpr (F16) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kq_ = lane >> 4, kh = 2 * st + (kq_ >> 1), kw = (kq_ & 1) * 2 + (j >> 2), c = j & 3;
+                const float w = (kh < 3 && kw < 3 && c < 3) ? a.w[((kh * 3 + kw) * 4 + c) * 16 + (lane & 15)] : 0.f;
+                const half_t h = (half_t)w;
+                wfh[st][j] = h; wfl[st][j] = (half_t)(w - (float)h);
+            }
+    } else {
 #pragma unroll
     for (int v = 0; v < 6; ++v) {
         const int c = v * 16 + (lane >> 2), r = lane & 3;
@@ -103,16 +126,19 @@ __global__ __launch_bounds__(256, RPW == 4 ? 3 : 6) void pnet_conv1_kernel(P1Arg
         }
         wreg[v] = x;
     }
+    }
 
     const int per_img = a.regions_x * a.regions_y;
-    const int nitems = per_img * a.B;
+    const int nitems = LIST ? min(*a.list_count, a.list_cap) : per_img * a.B;      // LIST: positions of the tile list
     const int item0 = blockIdx.x * RPB;
+    auto tile_of = [&](int item) { return LIST ? a.list[item] : item; };
     const float ryr = (float)a.FH / (float)a.H, rxr = (float)a.FW / (float)a.W;
     const int frame_bytes = a.FH * a.FW * 3;
 
     auto make_tables = [&](int item, int buf) __attribute__((always_inline)) {
         if (tid < NTAB) {
-            const int n = item / per_img, rem = item - n * per_img;
+            const int tile = tile_of(item);
+            const int n = tile / per_img, rem = tile - n * per_img;
             const int ry = rem / a.regions_x, rx = rem - ry * a.regions_x;
             int4v e;
             if (tid < IH) {
@@ -144,7 +170,7 @@ __global__ __launch_bounds__(256, RPW == 4 ? 3 : 6) void pnet_conv1_kernel(P1Arg
     bool edge = true;        // wave-uniform: some staged pixel is outside the level, sits on the clamped right border or
                              // was loaded with a pull-back (otherwise the blend needs no selects and no shifts)
     auto load_tile = [&](int item, int buf) __attribute__((always_inline)) {
-        const int n = item / per_img;
+        const int n = tile_of(item) / per_img;
         const uint8_t* fbase = a.frames + (int64_t)n * frame_bytes;
         const bool last = n == a.B - 1;
         const int lim = frame_bytes - 8;
@@ -201,7 +227,20 @@ __global__ __launch_bounds__(256, RPW == 4 ? 3 : 6) void pnet_conv1_kernel(P1Arg
                 // subnormals here: |sv - 127.5| >= 2^-17 or 0), so the bits are those of the two-operation form
                 v[c] = (!E || rfl[u] >= 0) && !(P1_ABL & 4) ? __builtin_fmaf(sv, 0.0078125f, -0.99609375f) : 0.f;
             }
-            xin[e * 3 + 0] = v[0]; xin[e * 3 + 1] = v[1]; xin[e * 3 + 2] = v[2];
+            if constexpr (F16) {
+                half4 hi, lo;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const half_t h = (half_t)v[c];
+                    hi[c] = h; lo[c] = (half_t)(v[c] - (float)h);
+                }
+                hi[3] = lo[3] = (half_t)0.f;
+                unsigned char* xz = reinterpret_cast<unsigned char*>(xin);
+                *reinterpret_cast<half4*>(xz + e * 8) = hi;
+                *reinterpret_cast<half4*>(xz + (XPX + e) * 8) = lo;
+            } else {
+                xin[e * 3 + 0] = v[0]; xin[e * 3 + 1] = v[1]; xin[e * 3 + 2] = v[2];
+            }
         }
     };
     auto store_tile = [&](int buf) __attribute__((always_inline)) {
@@ -230,13 +269,72 @@ __global__ __launch_bounds__(256, RPW == 4 ? 3 : 6) void pnet_conv1_kernel(P1Arg
     for (int rr = 0; rr < RPB; ++rr) {
         const int item = item0 + rr;
         if (item >= nitems) break;
-        const int n = item / per_img, rem = item - n * per_img;
+        const int tile_ = tile_of(item);
+        const int n = tile_ / per_img, rem = tile_ - n * per_img;
         const int ry = rem / a.regions_x, rx = rem - ry * a.regions_x;
         const int y0 = ry * TH, x0 = rx * P1_TW;
         const bool more = rr + 1 < RPB && item + 1 < nitems;
         const int nbuf = (rr + 1) & 1;
         if (more) load_tile(item + 1, nbuf);             // global loads fly under this tile's MFMAs
 
+        if constexpr (F16) {
+            // ---- conv on the f16 matrix cores: the wave's RPW rows x four 16-column tiles; lane (li, kq): pixel column 16 ct + li,
+            // couts 4 kq .. 4 kq + 3
+            typedef half8 half8_a8 __attribute__((aligned(8)));
+            const unsigned char* xz = reinterpret_cast<const unsigned char*>(xin);
+            const int li = lane & 15, kq = lane >> 4;
+            const float4v b4 = *reinterpret_cast<const float4v*>(a.bias + 4 * kq), s4 = *reinterpret_cast<const float4v*>(a.slope + 4 * kq);
+            const int64_t fbase = (int64_t)n * a.Hp;
+#pragma unroll
+            for (int rp = 0; rp < RPW / 2; ++rp) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    float4v d[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int row = wave * RPW + 2 * rp + h;
+                        const unsigned char* pb = xz + ((row + (kq >> 1)) * P1_IW + ct * 16 + li + 2 * (kq & 1)) * 8;
+                        const half8 h0 = *reinterpret_cast<const half8_a8*>(pb), l0 = *reinterpret_cast<const half8_a8*>(pb + XPX * 8);
+                        const half8 h1 = *reinterpret_cast<const half8_a8*>(pb + 2 * P1_IW * 8), l1 = *reinterpret_cast<const half8_a8*>(pb + (XPX + 2 * P1_IW) * 8);
+                        float4v q = {0.f, 0.f, 0.f, 0.f};
+                        q = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfl[0], h0, q, 0, 0, 0);
+                        q = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[0], l0, q, 0, 0, 0);
+                        q = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfl[1], h1, q, 0, 0, 0);
+                        q = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[1], l1, q, 0, 0, 0);
+                        q = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[0], h0, q, 0, 0, 0);
+                        q = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[1], h1, q, 0, 0, 0);
+                        // bias + PReLU, then the pool (a conv pixel outside the map: -inf); the same values in either order
+                        // when every slope is >= 0, and this order is right for any slope
+                        q += b4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) q[e] = q[e] > 0.f ? q[e] : q[e] * s4[e];
+                        const bool inside = y0 + row < a.Ho && x0 + ct * 16 + li < a.Wo;
+                        d[h] = inside ? q : float4v{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    }
+                    float4v m;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = vmax(d[0][e], d[1][e]);
+                        m[e] = vmax(t, dpp_xor1(t));
+                    }
+                    const int py = (y0 + wave * RPW + 2 * rp) >> 1, px = (x0 + ct * 16 + li) >> 1;
+                    if ((li & 1) == 0 && py < a.Hp && px < a.Wp) {
+                        const int64_t pix = (fbase + py) * a.Wp + px;
+                        half4 hi, lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x = 4 * kq + e < 10 ? m[e] : 0.f;
+                            const half_t hh = (half_t)x;
+                            hi[e] = hh; lo[e] = (half_t)(x - (float)hh);
+                        }
+                        unsigned char* o2 = a.y_split + pix * 64 + (kq >> 1) * 16 + (kq & 1) * 8;
+                        *reinterpret_cast<half4*>(o2) = hi;
+                        *reinterpret_cast<half4*>(o2 + 32) = lo;
+                        if (a.y && kq < 3) *reinterpret_cast<float4v*>(a.y + pix * 12 + 4 * kq) = m;      // (tests: the f32 view of the same map)
+                    }
+                }
+            }
+        } else {
         float4v acc[RPW][3];
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
@@ -367,6 +465,7 @@ __global__ __launch_bounds__(256, RPW == 4 ? 3 : 6) void pnet_conv1_kernel(P1Arg
                 if ((lane & 1) == 0 && py < a.Hp && px < a.Wp) put(pv, py, px);
             }
         }
+        }   // !F16
         if (more) {
             __syncthreads();                 // every wave is done reading this tile and the tables of the next one's loads
             store_tile(nbuf);
@@ -376,14 +475,14 @@ __global__ __launch_bounds__(256, RPW == 4 ? 3 : 6) void pnet_conv1_kernel(P1Arg
     }
 }
 
-template <int RPW, int RPB>
+template <int RPW, int RPB, bool F16 = false, bool LIST = false>
 int launch_p1(P1Args a, hipStream_t s) {
     constexpr int TH = 4 * RPW;
     a.regions_x = (a.Wo + P1_TW - 1) / P1_TW;
     a.regions_y = (a.Ho + TH - 1) / TH;
-    const int64_t nitems = (int64_t)a.regions_x * a.regions_y * a.B;
+    const int64_t nitems = LIST ? a.list_cap : (int64_t)a.regions_x * a.regions_y * a.B;
     if (nitems >= (1ll << 31)) return FR_E_INVALID;
-    pnet_conv1_kernel<RPW, RPB><<<(unsigned)((nitems + RPB - 1) / RPB), 256, 0, s>>>(a);
+    pnet_conv1_kernel<RPW, RPB, F16, LIST><<<(unsigned)((nitems + RPB - 1) / RPB), 256, 0, s>>>(a);
     return FR_OK;
 }
 
@@ -392,7 +491,7 @@ int launch_p1(P1Args a, hipStream_t s) {
 // called by fr_dconv_mfma_f32 (layer 0); arguments checked there
 int fr_pnet_conv1_launch(const uint8_t* frames, int B, int FH, int FW, int H, int W, const float* w, const float* bias,
                          const float* slope, float* y, void* y_split, hipStream_t s) {
-    P1Args a{frames, B, FH, FW, H, W, w, bias, slope, y, (unsigned char*)y_split, H - 2, W - 2, 0, 0, 0, 0};
+    P1Args a{frames, B, FH, FW, H, W, w, bias, slope, y, (unsigned char*)y_split, H - 2, W - 2, 0, 0, 0, 0, nullptr, nullptr, 0};
     a.Hp = (a.Ho + 1) / 2; a.Wp = (a.Wo + 1) / 2;
     // big launches: 16-row tiles, blocks persistent over 8 tiles; small pyramid levels / single frames: 8-row tiles, one
     // tile per block (too few tiles to fill 256 CUs: more, shorter blocks)
@@ -400,4 +499,29 @@ int fr_pnet_conv1_launch(const uint8_t* frames, int B, int FH, int FW, int H, in
     if (tiles16 >= 4096) return launch_p1<4, 8>(a, s);
     if (tiles16 >= 512) return launch_p1<4, 1>(a, s);
     return launch_p1<2, 1>(a, s);
+}
+
+// The band mode's pair (round 4).  mode 0: the conv on the f16 matrix cores with split-precision operands, the split map only
+// (y optional: the f32 view of the same values, tests).  mode 1: the exact f32 form over a LIST of tiles of 16 x 64 conv pixels
+// (tile numbers in the order ((frame * regions_y) + ry) * regions_x + rx with regions of 16 rows x 64 columns: fr_pnet_band_tiles)
+// - writes y (and y_split) for those tiles only.
+extern "C" int fr_pnet_conv1_band(int mode, const uint8_t* frames, int B, int FH, int FW, int H, int W, const float* w,
+                                  const float* bias, const float* slope, float* y, void* y_split, const int32_t* list,
+                                  const int32_t* list_count, int list_cap, fr_stream_t stream) {
+    FR_REQUIRE(frames && w && bias && slope && B > 0 && FH > 0 && FW > 0 && H >= 3 && W >= 3, "fr_pnet_conv1_band: bad argument");
+    P1Args a{frames, B, FH, FW, H, W, w, bias, slope, y, (unsigned char*)y_split, H - 2, W - 2, 0, 0, 0, 0, list, list_count, list_cap};
+    a.Hp = (a.Ho + 1) / 2; a.Wp = (a.Wo + 1) / 2;
+    hipStream_t s = fr_stream(stream);
+    int rc;
+    if (mode == 0) {
+        FR_REQUIRE(y_split, "fr_pnet_conv1_band: mode 0 writes the split map");
+        const int64_t tiles16 = (int64_t)((a.Ho + 15) / 16) * ((a.Wo + P1_TW - 1) / P1_TW) * B;
+        rc = tiles16 >= 4096 ? launch_p1<4, 8, true>(a, s) : launch_p1<4, 1, true>(a, s);
+    } else if (mode == 1) {
+        FR_REQUIRE(y && list && list_count && list_cap > 0, "fr_pnet_conv1_band: mode 1 needs the f32 map and a tile list");
+        rc = launch_p1<4, 1, false, true>(a, s);
+    } else { FR_REQUIRE(false, "fr_pnet_conv1_band: mode must be 0 or 1"); }
+    if (rc != FR_OK) { fr_set_error("fr_pnet_conv1_band: too many tiles"); return rc; }
+    FR_CHECK_LAUNCH("pnet_conv1_kernel (band)");
+    return FR_OK;
 }

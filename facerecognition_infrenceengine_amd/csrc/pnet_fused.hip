@@ -532,3 +532,52 @@ extern "C" int fr_pnet_finish_levels(const fr_pnet_level* levels, int nlevels, i
     FR_CHECK_LAUNCH("pnet_refine_levels");
     return fr_pnet_candidates_levels_launch(levels, nlevels, nframes, thr, cap, dl_min, s);
 }
+
+// ---------------------------------------------------------------- band mode with a split-precision conv1 (round 4)
+// The cells on the exact pass's lists need an EXACT f32 conv1 map under their 5 x 5 windows.  When conv1 itself ran on the f16
+// matrix cores (fr_pnet_conv1_band mode 0) that map does not exist: this kernel marks the conv1 tiles (16 x 64 conv pixels = 8 x 32
+// map pixels, the f32 conv1 kernel's tile) a listed cell's window touches - at most four - in a bitmap and appends every newly
+// marked tile to `tiles` (atomicOr returns whether the bit was set: dedupe and compaction in one pass); fr_pnet_conv1_band
+// mode 1 then computes exactly those tiles.  tbuf = [count | bitmap words], zeroed here.
+__global__ __launch_bounds__(256) void pnet_band_tiles_kernel(const int* __restrict__ list, const int* __restrict__ counts, int seg_cap,
+                                                             int H3, int W3, int regions_x, int regions_y, int32_t* __restrict__ tbuf,
+                                                             int32_t* __restrict__ tiles) {
+    const int n_list = counts[blockIdx.x];
+    const int* lst = list + (size_t)blockIdx.x * seg_cap;
+    const int hw3 = H3 * W3;
+    for (int i = threadIdx.x; i < n_list; i += 256) {
+        const int c = lst[i];
+        const int n = c / hw3, r = c - n * hw3, y = r / W3, x = r - y * W3;
+        // map rows y .. y + 4 <- conv rows 2y .. 2y + 9; columns likewise
+        const int ry0 = (2 * y) >> 4, ry1 = min((2 * y + 9) >> 4, regions_y - 1);
+        const int rx0 = (2 * x) >> 6, rx1 = min((2 * x + 9) >> 6, regions_x - 1);
+        for (int ry = ry0; ry <= ry1; ++ry)
+            for (int rx = rx0; rx <= rx1; ++rx) {
+                const int t = (n * regions_y + ry) * regions_x + rx;
+                const unsigned bit = 1u << (t & 31);
+                const unsigned old = atomicOr(reinterpret_cast<unsigned*>(tbuf) + 1 + (t >> 5), bit);
+                if (!(old & bit)) tiles[atomicAdd(tbuf, 1)] = t;
+            }
+    }
+}
+
+extern "C" size_t fr_pnet_band_tiles_count(int B, int H1, int W1) {        // tiles of the level = capacity of `tiles`
+    if (B <= 0 || H1 < 5 || W1 < 5) return 0;
+    // conv1 map H1 x W1 <- conv extent Ho = 2 H1 (or 2 H1 - 1), tiles of 16 x 64 conv pixels = 8 x 32 map pixels
+    return (size_t)B * ((H1 + 7) / 8) * ((W1 + 31) / 32);
+}
+
+extern "C" int fr_pnet_band_tiles(const void* workspace, int B, int H1, int W1, int32_t* tbuf, int32_t* tiles, fr_stream_t stream) {
+    FR_REQUIRE(workspace && tbuf && tiles && B > 0 && H1 >= 5 && W1 >= 5, "fr_pnet_band_tiles: bad argument");
+    long long ncell, nt; int grid, seg_cap;
+    p23_layout(B, H1, W1, ncell, nt, grid, seg_cap);
+    const float* dl = reinterpret_cast<const float*>(workspace);
+    const int* counts = reinterpret_cast<const int*>(dl + ncell);
+    const int regions_y = (H1 + 7) / 8, regions_x = (W1 + 31) / 32;
+    const size_t ntile = (size_t)B * regions_y * regions_x;
+    hipStream_t s = fr_stream(stream);
+    if (hipMemsetAsync(tbuf, 0, (1 + (ntile + 31) / 32) * sizeof(int32_t), s) != hipSuccess) { fr_set_error("fr_pnet_band_tiles: memset failed"); return FR_E_LAUNCH; }
+    pnet_band_tiles_kernel<<<grid, 256, 0, s>>>(counts + 512, counts, seg_cap, H1 - 4, W1 - 4, regions_x, regions_y, tbuf, tiles);
+    FR_CHECK_LAUNCH("pnet_band_tiles_kernel");
+    return FR_OK;
+}

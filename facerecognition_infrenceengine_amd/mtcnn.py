@@ -160,6 +160,10 @@ class MTCNNHIP:
         # keep / reject decision is that of f32 arithmetic); kept cells above the band carry the split-precision heads (~2e-6 from
         # the f32 ones) - as the R-/O-Net crops do (``split_ro``).  False: every cell that can be kept carries the f32 path's bits.
         self.pnet_band = True
+        self.split_pconv1 = True            # with pnet_band: conv1 on the f16 matrix cores too; the exact pass gets an exact f32 map
+                                            # under its cells' windows from the f32 conv1 kernel run over just those tiles
+        self.split_pconv1_min_px = 80000    # ... on levels whose conv1 map has at least this many pixels (the level pays four more
+                                            # small launches for it: worth it on the two largest levels of a 1080p pyramid)
         # exact pass + candidates of ALL levels in three launches behind the pyramid (fr_pnet_finish_levels) instead of three per
         # level.  Measured (64 x 1080p, same box): 5.92 - 5.95 ms against 5.77 - 5.80 per level - the per-level launches ride on
         # their level's stream under the other levels' kernels, the merged ones come behind the join.  Off; kept as an option.
@@ -303,20 +307,50 @@ class MTCNNHIP:
         return bo, so, ao, co
 
     # ---- nets
-    def pnet_level(self, frames, scale, trace=None):
-        """frames u8 [N,H,W,3] -> head f32 [N,hc,wc,6] of one pyramid level."""
+    def pnet_level(self, frames, scale, trace=None, cand=None):
+        """frames u8 [N,H,W,3] -> head f32 [N,hc,wc,6] of one pyramid level.
+        cand (detect_batch, batches): (scale, thr, cap, boxes, scores, regs, counts) of the level's candidate list - with conv1 on the
+        f16 matrix cores (``split_pconv1``) the level extracts its candidates itself (``_tls.level_done``)."""
         N, H, W, _ = frames.shape
         hs, ws = int(math.ceil(H * scale)), int(math.ceil(W * scale))
         # the pyramid level is resized inside P-Net conv1's tile load (no f32 level image in HBM)
         h, w = self.p1.out_hw(hs, ws)
+        self._tls.level_done = False
         if self.fused_pnet and N * h * w * 64 < 2 ** 31:          # the split map is addressed with 32-bit buffer offsets
-            xs = self._new((N, h, w, 64), torch.uint8)     # split-f16 copy of conv1's map
-            x, h, w = self._dconv(None, self.p1, N, hs, ws, frames=frames, y_split=xs)
             t0 = self.thresholds[0]
-            head = self._f32(N, h - 4, w - 4, 6)
-            ws = self._new((self.lib.fr_pnet23_workspace_bytes(N, h, w) // 4,), torch.float32)
             lt = math.log(t0 / (1.0 - t0))
             band = self.pnet_band and N >= 8 and trace is None
+            xs = self._new((N, h, w, 64), torch.uint8)     # split-f16 copy of conv1's map
+            if band and self.split_pconv1 and cand is not None and h * w >= self.split_pconv1_min_px:
+                # conv1 on the f16 matrix cores -> fused conv2/3/heads -> the conv1 tiles under the band cells' windows, EXACTLY -> the
+                # exact pass + the candidates (csrc/pnet_conv1.hip F16 / LIST, fr_pnet_band_tiles, fr_pnet_finish_levels)
+                p1 = self.p1
+                x = self._f32(N, h, w, 12)                  # the f32 map: written only where an exact window is needed
+                self.lib.fr_pnet_conv1_band(0, self._fptr(frames), N, H, W, hs, ws, _lib.ptr(p1.w), _lib.ptr(p1.b), _lib.ptr(p1.slope),
+                                            None, _lib.ptr(xs), None, None, 0, self._s)
+                head = self._f32(N, h - 4, w - 4, 6)
+                wsp = self._new((self.lib.fr_pnet23_workspace_bytes(N, h, w) // 4,), torch.float32)
+                self.lib.fr_pnet23_split_f16(_lib.ptr(x), _lib.ptr(xs), N, h, w, *[_lib.ptr(t) for t in self._p23], _lib.ptr(head),
+                                             (1 if self.p23_all_heads else 0) | 2, lt - self.refine_margin, lt + self.refine_margin,
+                                             _lib.ptr(self.refined_cells), _lib.ptr(wsp), wsp.numel() * 4, self._s)
+                nt = self.lib.fr_pnet_band_tiles_count(N, h, w)
+                tbuf, tiles = self._i32(1 + (nt + 31) // 32), self._i32(nt)
+                self.lib.fr_pnet_band_tiles(_lib.ptr(wsp), N, h, w, _lib.ptr(tbuf), _lib.ptr(tiles), self._s)
+                self.lib.fr_pnet_conv1_band(1, self._fptr(frames), N, H, W, hs, ws, _lib.ptr(p1.w), _lib.ptr(p1.b), _lib.ptr(p1.slope),
+                                            _lib.ptr(x), None, _lib.ptr(tiles), _lib.ptr(tbuf), nt, self._s)
+                sc, thr, cap, lb, ls, lr, lc = cand
+                bc = self._i32(N * (-(-(h - 4) * (w - 4) // 256)))
+                lv = (_lib.PnetLevel * 1)(_lib.PnetLevel(x.data_ptr(), head.data_ptr(), wsp.data_ptr(), h, w, float(sc), lb.data_ptr(),
+                                                          ls.data_ptr(), lr.data_ptr(), lc.data_ptr(), bc.data_ptr()))
+                self.lib.fr_pnet_finish_levels(lv, 1, N, *[_lib.ptr(t) for t in self._p23], thr, cap, lt - self.refine_margin,
+                                               _lib.ptr(self.refined_cells), self._s)
+                self._dl = (wsp, lt - self.refine_margin)
+                self._tls.level_done = True
+                self._tls.keep = (x, xs, head, wsp, tbuf, tiles, bc)      # alive until the stream has been joined (detect_batch)
+                return head, h - 4, w - 4
+            x, h, w = self._dconv(None, self.p1, N, hs, ws, frames=frames, y_split=xs)
+            head = self._f32(N, h - 4, w - 4, 6)
+            ws = self._new((self.lib.fr_pnet23_workspace_bytes(N, h, w) // 4,), torch.float32)
             defer = getattr(self._tls, "defer", None)     # detect_batch: the exact pass of every level in one launch, behind the pyramid
             self.lib.fr_pnet23_split_f16(_lib.ptr(x), _lib.ptr(xs), N, h, w, *[_lib.ptr(t) for t in self._p23], _lib.ptr(head),
                                          (1 if (self.p23_all_heads or trace is not None) else 0) | (2 if defer is not None else 0),
@@ -538,7 +572,7 @@ class MTCNNHIP:
                       and all(N * self.p1.out_hw(int(math.ceil(H * sc)), int(math.ceil(W * sc)))[0]
                               * self.p1.out_hw(int(math.ceil(H * sc)), int(math.ceil(W * sc)))[1] * 64 < 2 ** 31 for sc in scales))
             self._tls.defer = [] if finish else None
-            bcs = []
+            bcs, keep = [], []
             for li, s in enumerate(scales):
                 side = sides[(li - 1) % len(sides)] if li else sides[0]
                 with (contextlib.nullcontext() if solo else torch.cuda.stream(main if li == 0 else side)):
@@ -546,12 +580,15 @@ class MTCNNHIP:
                         self._s = _lib.stream_ptr()
                     elif record:
                         self._s = ctypes.c_void_p((main if li == 0 else rec_sides[(li - 1) % len(rec_sides)]).cuda_stream)
-                    head, hc, wc = self.pnet_level(frames, s, trace)
+                    head, hc, wc = self.pnet_level(frames, s, trace, cand=None if (finish or trace is not None or N < 8) else
+                                                   (float(s), t0, cs, lb[li], ls[li], lr[li], lc[li]))
                     nblk = -(-hc * wc // 256)
                     bc = self._i32(N * nblk)
                     prob = self._f32(N, hc, wc) if trace is not None else None
                     dl, dl_min = self._dl
-                    if finish:
+                    if self._tls.level_done:                    # the level extracted its candidates itself
+                        keep.append(self._tls.keep)
+                    elif finish:
                         bcs.append(bc)
                     else:
                         lib.fr_pnet_candidates(_lib.ptr(head), N, hc, wc, float(s), t0, cs, _lib.ptr(lb[li]), _lib.ptr(ls[li]),
@@ -575,6 +612,9 @@ class MTCNNHIP:
                     main.wait_event(ev)
                     lib.note(9, main.cuda_stream, ev.cuda_event)
                 self._s = ctypes.c_void_p(main.cuda_stream)
+            for grp in keep:                                    # allocated on a level stream, must outlive the kernels queued there
+                for t in grp:
+                    t.record_stream(main)
             if finish:
                 lv = (_lib.PnetLevel * nlev)()
                 for li, ((x1, head, ws, h1, w1), bc, sc) in enumerate(zip(self._tls.defer, bcs, scales)):

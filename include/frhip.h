@@ -430,6 +430,19 @@ int fr_stage_select(const float* boxes, const float* head, int nh, const int32_t
                     float thr, float* boxes_out, float* scores_out, float* aux_out, int naux,
                     int32_t* counts_out, float* prob_out, fr_stream_t stream);
 
+/* Band mode with conv1 on the f16 matrix cores (round 4, batches).  fr_pnet_conv1_band mode 0: P-Net conv1 (+ the pyramid
+ * resize, PReLU, 2x2 ceil pool: layer 0 of fr_dconv_mfma_f32) with split-precision operands - writes the split map y_split
+ * only (y optional: the f32 view of the same ~1e-6-accurate values).  The exact pass then needs an exact f32 map under the
+ * windows of the cells on its lists: fr_pnet_band_tiles marks the conv1 tiles (8 x 32 map pixels) those windows touch
+ * (tbuf: 1 + ceil(tiles / 32) int32 = [count | bitmap], zeroed here; tiles: int32 [fr_pnet_band_tiles_count(B, H1, W1)]), and
+ * fr_pnet_conv1_band mode 1 runs the EXACT f32 kernel over that list (list = tiles, list_count = tbuf, list_cap = the tile
+ * count), writing y for those tiles only.  Call order per level: mode 0, fr_pnet23_split_f16 (all_heads | 2, band), band_tiles,
+ * mode 1, fr_pnet_finish_levels (one level).  H, W: the level's size; H1, W1: the conv1 map's. */
+int fr_pnet_conv1_band(int mode, const uint8_t* frames, int B, int FH, int FW, int H, int W, const float* w, const float* bias,
+                       const float* slope, float* y, void* y_split, const int32_t* list, const int32_t* list_count, int list_cap,
+                       fr_stream_t stream);
+size_t fr_pnet_band_tiles_count(int B, int H1, int W1);
+int fr_pnet_band_tiles(const void* workspace, int B, int H1, int W1, int32_t* tbuf, int32_t* tiles, fr_stream_t stream);
 /* The exact pass (deferred by all_heads bit 1) and fr_pnet_candidates for ALL pyramid levels of a batch in three launches
  * instead of three per level: the same cells, the same ordered compaction per level and frame.  A level entry repeats what
  * its fr_pnet23_split_f16 / fr_pnet_candidates calls would have been given (workspace = that level's, unchanged since;

@@ -702,3 +702,112 @@ def test_split_gemm_tail_layers_vs_f32_layers():
         err, scale = float((got[valid] - want[valid]).abs().max()), float(want[valid].abs().max())
         print(f"\nlayer {lid}: split GEMM vs f32 layer: max |d| {err:.3e} at scale {scale:.3f}")
         assert err <= 4e-6 * scale, (lid, err, scale)
+
+
+def test_pnet_conv1_on_matrix_cores_with_exact_tiles_under_the_band():
+    """``split_pconv1`` (batches, band mode): P-Net conv1 runs on the f16 matrix cores too (split precision, map written only as
+    hi/lo halves); the exact pass then needs exact f32 conv1 values under its cells' 5x5 windows, which the f32 conv1 kernel
+    produces for just the 16x64 tiles those windows touch (fr_pnet_band_tiles -> fr_pnet_conv1_band mode 1).  Checked here:
+    (1) the split map decodes to the f32 map within 2e-6 relative; (2) per level the candidate lists of the two settings agree -
+    same counts, same cells, the cells inside the band bit for bit; (3) the marked tiles cover every band cell's window and the
+    f32 map holds the f32 kernel's bits there; (4) the cascade on eight frames returns the same faces."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import synth_frame
+    from facerecognition_infrenceengine_amd import weights, _lib
+    from facerecognition_infrenceengine_amd.mtcnn import MTCNNHIP, pyramid_scales
+    st = weights.synth_mtcnn_states(seed=4321)
+    mc = MTCNNHIP(*st, device="cuda:0")
+    ref = MTCNNHIP(*st, device="cuda:0")
+    assert mc.split_pconv1 and mc.pnet_band
+    mc.split_pconv1_min_px = 25                                         # every level (the default takes the large ones only)
+    ref.split_pconv1 = False
+    mc.split_ro = ref.split_ro = False                                  # this test isolates the P-Net
+    hw = (360, 640)
+    N = 8
+    fr = torch.from_numpy(np.ascontiguousarray(np.stack([synth_frame(hw[0], hw[1], 170 + k) for k in range(N)]))).cuda()
+    lib = mc.lib
+    # (1) the split map against the f32 map of the same kernel family
+    hs, ws = 180, 320
+    h, w = mc.p1.out_hw(hs, ws)
+    xs = torch.zeros(N, h, w, 64, dtype=torch.uint8, device="cuda")
+    y = torch.zeros(N, h, w, 12, device="cuda")
+    s0 = torch.cuda.current_stream().cuda_stream
+    lib.fr_pnet_conv1_band(0, _lib.ptr(fr), N, hw[0], hw[1], hs, ws, _lib.ptr(mc.p1.w), _lib.ptr(mc.p1.b), _lib.ptr(mc.p1.slope),
+                           _lib.ptr(y), _lib.ptr(xs), None, None, 0, s0)
+    with torch.cuda.device("cuda:0"):
+        ref._s = s0
+        yr, _, _ = ref._dconv(None, ref.p1, N, hs, ws, frames=fr)
+    torch.cuda.synchronize()
+    hl = xs.view(torch.float16).reshape(N, h, w, 2, 16)[..., :12].float()
+    dec = hl[..., 0, :] + hl[..., 1, :]
+    scale = float(yr.abs().max())
+    assert float((dec - yr).abs().max()) <= 4e-6 * scale, (float((dec - yr).abs().max()), scale)
+    assert float((y - yr).abs().max()) <= 4e-6 * scale
+    # (2), (3) level by level
+    t0 = mc.thresholds[0]
+    lt = float(np.log(t0 / (1 - t0)))
+    cs = mc.cap_scale
+    inband = total = tiles_marked = tiles_all = 0
+    for s in pyramid_scales(*hw):
+        outs = []
+        for d in (mc, ref):
+            lb, ls, lr, lc = (torch.zeros(N, cs, 4, device="cuda"), torch.zeros(N, cs, device="cuda"),
+                              torch.zeros(N, cs, 4, device="cuda"), torch.zeros(N, dtype=torch.int32, device="cuda"))
+            with torch.cuda.device("cuda:0"):
+                d._s = s0
+                head, hc, wc = d.pnet_level(fr, s, cand=(float(s), t0, cs, lb, ls, lr, lc))
+                if d is ref:
+                    assert not d._tls.level_done
+                    bc = torch.zeros(N * (-(-hc * wc // 256)), dtype=torch.int32, device="cuda")
+                    lib.fr_pnet_candidates(_lib.ptr(head), N, hc, wc, float(s), t0, cs, _lib.ptr(lb), _lib.ptr(ls), _lib.ptr(lr),
+                                           _lib.ptr(lc), _lib.ptr(bc), None, _lib.ptr(d._dl[0]), d._dl[1], s0)
+                else:
+                    assert d._tls.level_done
+                    x1, _, _, wsp, tbuf, tiles, _ = d._tls.keep
+            torch.cuda.synchronize()
+            outs.append((lb, ls, lr, lc, head, d._dl[0][:N * hc * wc].reshape(N, hc, wc).clone()))
+        (ab, as_, ar, ac, ah, adl), (bb, bs, br, bc_, bh, bdl) = outs
+        assert torch.equal(ac, bc_), (s, ac, bc_)
+        for f in range(N):
+            n = min(int(ac[f]), cs)
+            assert torch.equal(ab[f, :n], bb[f, :n])                      # the same cells in the same order
+            sb = bs[f, :n]
+            lg = torch.log(sb / (1 - sb))
+            near = (lg - lt).abs() < 0.5 * mc.refine_margin              # well inside the band by the f32 path's own score
+            assert torch.equal(as_[f, :n][near], sb[near]) and torch.equal(ar[f, :n][near], br[f, :n][near])
+            assert float((as_[f, :n] - sb).abs().max() if n else 0.0) <= 5e-6
+            assert float((ar[f, :n] - br[f, :n]).abs().max() if n else 0.0) <= 2e-5
+            inband += int(near.sum()); total += n
+        # (3) band cells of the matrix-core run: their windows' tiles are on the list and hold the f32 kernel's bits
+        h1, w1 = hc + 4, wc + 4
+        band = (adl >= lt - mc.refine_margin) & (adl <= lt + mc.refine_margin)
+        cnt = int(tbuf[0])
+        nt = tiles.numel()
+        tiles_marked += cnt; tiles_all += nt
+        listed = set(tiles[:cnt].tolist())
+        assert len(listed) == cnt
+        ry, rx = (h1 + 7) // 8, (w1 + 31) // 32
+        hs_l, ws_l = int(np.ceil(hw[0] * s)), int(np.ceil(hw[1] * s))
+        with torch.cuda.device("cuda:0"):
+            yr, _, _ = ref._dconv(None, ref.p1, N, hs_l, ws_l, frames=fr)
+        torch.cuda.synchronize()
+        for n_, yy, xx in band.nonzero().tolist():
+            for ty in {yy // 8, (yy + 4) // 8}:
+                for tx in {xx // 32, (xx + 4) // 32}:
+                    assert (n_ * ry + ty) * rx + tx in listed
+            assert torch.equal(x1[n_, yy:yy + 5, xx:xx + 5], yr[n_, yy:yy + 5, xx:xx + 5])
+    assert total >= 100 and inband >= 1, (total, inband)
+    # (4) the cascade
+    a = mc.detect_batch(fr)
+    b = ref.detect_batch(fr)
+    torch.cuda.synchronize()
+    print(f"\nP-Net conv1 on the matrix cores: {total} candidates, {inband} inside the band bit-identical; "
+          f"{tiles_marked} of {tiles_all} conv1 tiles recomputed in f32")
+    assert torch.equal(a[3], b[3]) and int(a[3].sum()) >= 8
+    for f in range(N):
+        n = int(a[3][f])
+        if n:
+            assert float((a[1][f, :n] - b[1][f, :n]).abs().max()) <= 5e-6
+            assert float((a[0][f, :n] - b[0][f, :n]).abs().max()) <= 1e-3
+            assert float((a[2][f, :n] - b[2][f, :n]).abs().max()) <= 1e-3
