@@ -72,13 +72,17 @@ __device__ __forceinline__ float dpp_shr1(float v) {        // value of lane - 1
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
 }
 
-// v_max_f32 without the canonicalising self-max the compiler puts in front of fmaxf for values of unknown origin (MFMA
-// results): the operands here are never signalling NaNs
-__device__ __forceinline__ float vmax(float x, float y) {
+// max(x, y) as v_med3_f32(x, y, +inf) with the +inf in a register the compiler cannot see through: ONE instruction - fmaxf (and
+// med3 with a literal +inf, which hipcc folds to it) puts a canonicalising self-max in front of every operand of unknown origin
+// (MFMA results; never NaN here).  NOT an inline-asm v_max_f32: the hazard recogniser does not see an asm statement's operands,
+// and an asm max placed right behind the MFMA that produces its operand read the register before the matrix pipe had written it
+// (round 4: the first of four maxima wrong, in interior tiles only - elsewhere a select sat in between).
+__device__ __forceinline__ float opaque_inf() {
     float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    asm("v_mov_b32 %0, 0x7f800000" : "=v"(r));
     return r;
 }
+__device__ __forceinline__ float vmax(float x, float y, float pinf) { return __builtin_amdgcn_fmed3f(x, y, pinf); }
 
 // Lerp tables of a tile: the source rows / columns and weights of its (rows + 2) level rows and 66 level columns are
 // computed ONCE per tile by 84 threads (not once per pixel by everybody) and read back from LDS.
@@ -101,6 +105,7 @@ __global__ __launch_bounds__(256, RPW == 4 ? 3 : 6) void pnet_conv1_kernel(P1Arg
     __shared__ __attribute__((aligned(16))) float xin[F16 ? XPX * 4 : XPX * 3];      // slots past NPX (the last slot of some threads) land in the padding
     __shared__ __attribute__((aligned(16))) int4v tab[2][NTAB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float pinf = opaque_inf();
 
     // ---- weights: slot c = 3k + g (k = tap * 3 + channel) -> lanes 4 (c % 16) + r of register c / 16 hold W[k][4g + r]
     float wreg[6];
@@ -285,6 +290,76 @@ __global__ __launch_bounds__(256, RPW == 4 ? 3 : 6) void pnet_conv1_kernel(P1Arg
             const int li = lane & 15, kq = lane >> 4;
             const float4v b4 = *reinterpret_cast<const float4v*>(a.bias + 4 * kq), s4 = *reinterpret_cast<const float4v*>(a.slope + 4 * kq);
             const int64_t fbase = (int64_t)n * a.Hp;
+            auto conv16 = [&](int row, int ct) __attribute__((always_inline)) {          // 16 pixels x 16 couts: raw sums
+                const unsigned char* pb = xz + ((row + (kq >> 1)) * P1_IW + ct * 16 + li + 2 * (kq & 1)) * 8;
+                const half8 h0 = *reinterpret_cast<const half8_a8*>(pb), l0 = *reinterpret_cast<const half8_a8*>(pb + XPX * 8);
+                const half8 h1 = *reinterpret_cast<const half8_a8*>(pb + 2 * P1_IW * 8), l1 = *reinterpret_cast<const half8_a8*>(pb + (XPX + 2 * P1_IW) * 8);
+                float4v q = {0.f, 0.f, 0.f, 0.f};
+                q = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfl[0], h0, q, 0, 0, 0);
+                q = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[0], l0, q, 0, 0, 0);
+                q = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfl[1], h1, q, 0, 0, 0);
+                q = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[1], l1, q, 0, 0, 0);
+                q = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[0], h0, q, 0, 0, 0);
+                q = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[1], h1, q, 0, 0, 0);
+                return q;
+            };
+            auto put16 = [&](const float4v& m, int py, int px) __attribute__((always_inline)) {   // a pooled pixel's four couts
+                const int64_t pix = (fbase + py) * a.Wp + px;
+                half4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const half_t hh = (half_t)m[e];
+                    hi[e] = hh; lo[e] = (half_t)(m[e] - (float)hh);
+                }
+                unsigned char* o2 = a.y_split + pix * 64 + (kq >> 1) * 16 + (kq & 1) * 8;
+                *reinterpret_cast<half4*>(o2) = hi;
+                *reinterpret_cast<half4*>(o2 + 32) = lo;
+                if (a.y && kq < 3) *reinterpret_cast<float4v*>(a.y + pix * 12 + 4 * kq) = m;      // (tests: the f32 view of the same map)
+            };
+            if (mono) {
+                // Every slope >= 0: bias + PReLU commute with the max pool.  Pool the RAW sums, then move row pair 1's pooled pixels
+                // (even lanes) into the odd lanes beside row pair 0's: bias, PReLU, split and store run once per FOUR conv rows with
+                // every lane on a pooled pixel.  PReLU as x + (s - 1) min(x, 0): two operations (the split map is ~1e-6 anyway).
+                static_assert(RPW == 4 || !F16, "the packed epilogue pairs the wave's two row pairs");
+                const bool interior = y0 + TH <= a.Ho && x0 + P1_TW <= a.Wo;       // block-uniform: no pixel of the tile is outside
+                float4v s4m, b4z;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s4m[e] = 4 * kq + e < 10 ? s4[e] - 1.f : -1.f; b4z[e] = 4 * kq + e < 10 ? b4[e] : 0.f; }
+                // (couts 10..15: zero weights and zero bias -> 0 + (-1) min(0, 0) = 0, as the map wants them)
+                const int odd = li & 1;
+                const int py = ((y0 + wave * RPW) >> 1) + odd;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    float4v m[2];
+#pragma unroll
+                    for (int rp = 0; rp < 2; ++rp) {
+                        float4v d0 = conv16(wave * RPW + 2 * rp, ct), d1 = conv16(wave * RPW + 2 * rp + 1, ct);
+                        if (!interior) {
+                            const bool cin = x0 + ct * 16 + li < a.Wo;
+                            const bool in0 = cin && y0 + wave * RPW + 2 * rp < a.Ho, in1 = cin && y0 + wave * RPW + 2 * rp + 1 < a.Ho;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { d0[e] = in0 ? d0[e] : -INFINITY; d1[e] = in1 ? d1[e] : -INFINITY; }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = vmax(d0[e], d1[e], pinf);
+                            m[rp][e] = vmax(t, dpp_xor1(t), pinf);
+                        }
+                    }
+                    float4v v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // lane - 1's m[1] for the odd lanes.  The move is pinned in front of the select: written as `odd ? dpp(m1) : m0`
+                        // hipcc runs it under the odd lanes' EXEC mask, where its source lanes are disabled and read as 0
+                        float sh = dpp_shr1(m[1][e]);
+                        asm volatile("" : "+v"(sh));
+                        const float x = (odd ? sh : m[0][e]) + b4z[e];
+                        v[e] = __builtin_fmaf(fminf(x, 0.f), s4m[e], x);
+                    }
+                    const int px = ((x0 + ct * 16) >> 1) + (li >> 1);
+                    if (py < a.Hp && px < a.Wp) put16(v, py, px);
+                }
+            } else {
 #pragma unroll
             for (int rp = 0; rp < RPW / 2; ++rp) {
 #pragma unroll
@@ -293,18 +368,8 @@ __global__ __launch_bounds__(256, RPW == 4 ? 3 : 6) void pnet_conv1_kernel(P1Arg
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int row = wave * RPW + 2 * rp + h;
-                        const unsigned char* pb = xz + ((row + (kq >> 1)) * P1_IW + ct * 16 + li + 2 * (kq & 1)) * 8;
-                        const half8 h0 = *reinterpret_cast<const half8_a8*>(pb), l0 = *reinterpret_cast<const half8_a8*>(pb + XPX * 8);
-                        const half8 h1 = *reinterpret_cast<const half8_a8*>(pb + 2 * P1_IW * 8), l1 = *reinterpret_cast<const half8_a8*>(pb + (XPX + 2 * P1_IW) * 8);
-                        float4v q = {0.f, 0.f, 0.f, 0.f};
-                        q = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfl[0], h0, q, 0, 0, 0);
-                        q = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[0], l0, q, 0, 0, 0);
-                        q = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfl[1], h1, q, 0, 0, 0);
-                        q = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[1], l1, q, 0, 0, 0);
-                        q = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[0], h0, q, 0, 0, 0);
-                        q = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[1], h1, q, 0, 0, 0);
-                        // bias + PReLU, then the pool (a conv pixel outside the map: -inf); the same values in either order
-                        // when every slope is >= 0, and this order is right for any slope
+                        float4v q = conv16(row, ct);
+                        // bias + PReLU, then the pool (a conv pixel outside the map: -inf): the order that is right for any slope
                         q += b4;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) q[e] = q[e] > 0.f ? q[e] : q[e] * s4[e];
@@ -314,25 +379,13 @@ __global__ __launch_bounds__(256, RPW == 4 ? 3 : 6) void pnet_conv1_kernel(P1Arg
                     float4v m;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float t = vmax(d[0][e], d[1][e]);
-                        m[e] = vmax(t, dpp_xor1(t));
+                        const float t = vmax(d[0][e], d[1][e], pinf);
+                        m[e] = 4 * kq + e < 10 ? vmax(t, dpp_xor1(t), pinf) : 0.f;
                     }
                     const int py = (y0 + wave * RPW + 2 * rp) >> 1, px = (x0 + ct * 16 + li) >> 1;
-                    if ((li & 1) == 0 && py < a.Hp && px < a.Wp) {
-                        const int64_t pix = (fbase + py) * a.Wp + px;
-                        half4 hi, lo;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float x = 4 * kq + e < 10 ? m[e] : 0.f;
-                            const half_t hh = (half_t)x;
-                            hi[e] = hh; lo[e] = (half_t)(x - (float)hh);
-                        }
-                        unsigned char* o2 = a.y_split + pix * 64 + (kq >> 1) * 16 + (kq & 1) * 8;
-                        *reinterpret_cast<half4*>(o2) = hi;
-                        *reinterpret_cast<half4*>(o2 + 32) = lo;
-                        if (a.y && kq < 3) *reinterpret_cast<float4v*>(a.y + pix * 12 + 4 * kq) = m;      // (tests: the f32 view of the same map)
-                    }
+                    if ((li & 1) == 0 && py < a.Hp && px < a.Wp) put16(m, py, px);
                 }
+            }
             }
         } else {
         float4v acc[RPW][3];
@@ -410,8 +463,8 @@ __global__ __launch_bounds__(256, RPW == 4 ? 3 : 6) void pnet_conv1_kernel(P1Arg
                 for (int g = 0; g < 3; ++g)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float m = vmax(acc[2 * rp][g][e], acc[2 * rp + 1][g][e]);
-                        pv[rp][g][e] = vmax(m, dpp_xor1(m));
+                        const float m = vmax(acc[2 * rp][g][e], acc[2 * rp + 1][g][e], pinf);
+                        pv[rp][g][e] = vmax(m, dpp_xor1(m), pinf);
                     }
             float4v q[3];
             int py = (y0 + wave * RPW) >> 1;
@@ -458,8 +511,8 @@ __global__ __launch_bounds__(256, RPW == 4 ? 3 : 6) void pnet_conv1_kernel(P1Arg
                 for (int g = 0; g < 3; ++g)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float m = vmax(acc[2 * rp][g][e], acc[2 * rp + 1][g][e]);
-                        pv[g][e] = vmax(m, dpp_xor1(m));
+                        const float m = vmax(acc[2 * rp][g][e], acc[2 * rp + 1][g][e], pinf);
+                        pv[g][e] = vmax(m, dpp_xor1(m), pinf);
                     }
                 const int py = (y0 + wave * RPW + 2 * rp) >> 1, px = xcol >> 1;
                 if ((lane & 1) == 0 && py < a.Hp && px < a.Wp) put(pv, py, px);

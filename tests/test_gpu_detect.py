@@ -440,6 +440,19 @@ def test_pnet_conv1_kernel_vs_oracle_and_16x16x4_form(negative_slopes):
             got = outs[0][0][0, :, :, :10].cpu().numpy()
             np.testing.assert_allclose(got, want, atol=3e-5, rtol=1e-5)
             assert float(outs[0][0][..., 10:].abs().max()) == 0.0
+            # the f16 matrix-core form (fr_pnet_conv1_band mode 0, the batch path's band mode): split map = the f32 map within ~1e-6,
+            # channels 10..15 zero, nothing written outside the map; its f32 view (tests only) is the map the halves encode
+            y16 = torch.full((N, h, w, 12), float("nan"), dtype=torch.float32, device="cuda")
+            xs16 = torch.full((N, h, w, 64), 0x7f, dtype=torch.uint8, device="cuda")
+            assert lib.fr_pnet_conv1_band(0, _lib.ptr(frames), N, H, W, hs, ws, _lib.ptr(p1.w), _lib.ptr(p1.b), _lib.ptr(p1.slope),
+                                          _lib.ptr(y16), _lib.ptr(xs16), None, None, 0, _lib.stream_ptr()) == 0
+            torch.cuda.synchronize()
+            hl = xs16.view(torch.float16).reshape(N, h, w, 2, 16).float()
+            assert float(hl[..., 10:].abs().max()) == 0.0
+            dec = hl[..., 0, :12] + hl[..., 1, :12]
+            tol = 4e-6 * max(1.0, float(outs[0][0].abs().max()))
+            assert float((dec - outs[0][0]).abs().max()) <= tol, (N, H, W, hs, ws, float((dec - outs[0][0]).abs().max()), tol)
+            assert float((y16 - outs[0][0]).abs().max()) <= tol
 
 
 @pytest.mark.parametrize("negative_slopes", [False, True])
