@@ -60,7 +60,14 @@ __device__ __forceinline__ float bilerp(float p00, float p01, float p10, float p
     return (1.0f - wy) * top + wy * bot;
 }
 
+typedef int int2v __attribute__((ext_vector_type(2)));
 constexpr int P1_TW = 64, P1_IW = P1_TW + 2;
+#ifndef P1_OCC
+#define P1_OCC 3
+#endif
+#ifndef P1_CTU
+#define P1_CTU 4
+#endif
 #ifndef P1_ABL
 #define P1_ABL 0
 #endif
@@ -96,7 +103,7 @@ __device__ __forceinline__ float vmax(float x, float y, float pinf) { return __b
 // cells whose decision that could touch are re-evaluated from an EXACT map: the f32 form below, run over the tiles such a cell's
 // window touches (LIST: tile numbers from fr_pnet_band_tiles).
 template <int RPW, int RPB, bool F16 = false, bool LIST = false>
-__global__ __launch_bounds__(256, RPW == 4 ? 3 : 6) void pnet_conv1_kernel(P1Args a) {
+__global__ __launch_bounds__(256, RPW == 4 ? (F16 ? P1_OCC : 3) : 6) void pnet_conv1_kernel(P1Args a) {
     constexpr int TH = 4 * RPW, IH = TH + 2, NPX = IH * P1_IW;
     constexpr int NPF = (NPX + 255) / 256;
     constexpr int NTAB = IH + P1_IW;
@@ -216,6 +223,13 @@ __global__ __launch_bounds__(256, RPW == 4 ? 3 : 6) void pnet_conv1_kernel(P1Arg
         for (int u = 0; u < NPF; ++u) {
             const int e = tid + u * 256;
             float v[3];
+            if ((P1_ABL & 16) && F16) {                                                                        // (ablation: no conversion / blend)
+                unsigned char* xz = reinterpret_cast<unsigned char*>(xin);
+                half4 hh; hh[0] = hh[1] = hh[2] = hh[3] = (half_t)__int_as_float((int)(rq0[u] ^ rq1[u]) & 0x3fffffff);
+                *reinterpret_cast<half4*>(xz + e * 8) = hh;
+                *reinterpret_cast<half4*>(xz + (XPX + e) * 8) = hh;
+                continue;
+            }
             const unsigned long long q0 = E ? rq0[u] >> ((rfl[u] >> 8) & 0xff) : rq0[u];
             const unsigned long long q1 = E ? rq1[u] >> ((rfl[u] >> 16) & 0xff) : rq1[u];
             const unsigned l0 = (unsigned)q0, h0 = (unsigned)(q0 >> 32), l1 = (unsigned)q1, h1 = (unsigned)(q1 >> 32);
@@ -292,9 +306,14 @@ __global__ __launch_bounds__(256, RPW == 4 ? 3 : 6) void pnet_conv1_kernel(P1Arg
             const int64_t fbase = (int64_t)n * a.Hp;
             auto conv16 = [&](int row, int ct) __attribute__((always_inline)) {          // 16 pixels x 16 couts: raw sums
                 const unsigned char* pb = xz + ((row + (kq >> 1)) * P1_IW + ct * 16 + li + 2 * (kq & 1)) * 8;
-                const half8 h0 = *reinterpret_cast<const half8_a8*>(pb), l0 = *reinterpret_cast<const half8_a8*>(pb + XPX * 8);
-                const half8 h1 = *reinterpret_cast<const half8_a8*>(pb + 2 * P1_IW * 8), l1 = *reinterpret_cast<const half8_a8*>(pb + (XPX + 2 * P1_IW) * 8);
+                half8 h0, l0, h1, l1;
+                if (P1_ABL & 8) { h0 = l0 = h1 = l1 = wfh[0]; asm volatile("" :: "v"(pb)); }                 // (ablation: no fragment reads)
+                else {
+                h0 = *reinterpret_cast<const half8_a8*>(pb); l0 = *reinterpret_cast<const half8_a8*>(pb + XPX * 8);
+                h1 = *reinterpret_cast<const half8_a8*>(pb + 2 * P1_IW * 8); l1 = *reinterpret_cast<const half8_a8*>(pb + (XPX + 2 * P1_IW) * 8);
+                }
                 float4v q = {0.f, 0.f, 0.f, 0.f};
+                if (P1_ABL & 2) { asm volatile("" :: "v"(h0), "v"(l0), "v"(h1), "v"(l1)); return q; }      // (ablation: no MFMAs)
                 q = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfl[0], h0, q, 0, 0, 0);
                 q = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[0], l0, q, 0, 0, 0);
                 q = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfl[1], h1, q, 0, 0, 0);
@@ -305,15 +324,20 @@ __global__ __launch_bounds__(256, RPW == 4 ? 3 : 6) void pnet_conv1_kernel(P1Arg
             };
             auto put16 = [&](const float4v& m, int py, int px) __attribute__((always_inline)) {   // a pooled pixel's four couts
                 const int64_t pix = (fbase + py) * a.Wp + px;
+                if (P1_ABL & 32) { asm volatile("" :: "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(pix)); return; }   // (ablation: no split / stores)
                 half4 hi, lo;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const half_t hh = (half_t)m[e];
                     hi[e] = hh; lo[e] = (half_t)(m[e] - (float)hh);
                 }
-                unsigned char* o2 = a.y_split + pix * 64 + (kq >> 1) * 16 + (kq & 1) * 8;
-                *reinterpret_cast<half4*>(o2) = hi;
-                *reinterpret_cast<half4*>(o2 + 32) = lo;
+                // 16 B per lane: v_permlane16_swap trades the odd kq rows' hi halves with the even rows' lo halves - an even-kq lane then
+                // holds hi of couts 4 kq .. 4 kq + 7, the odd one beside it their lo (partners share the pixel, hence the branch);
+                // the four lanes of a pixel write its whole 64-B entry in ONE instruction (two 8-B stores per lane before)
+                const int2v hp = __builtin_bit_cast(int2v, hi), lp = __builtin_bit_cast(int2v, lo);
+                const auto s0 = __builtin_amdgcn_permlane16_swap((unsigned)hp[0], (unsigned)lp[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap((unsigned)hp[1], (unsigned)lp[1], false, false);
+                *reinterpret_cast<int4v*>(a.y_split + pix * 64 + (kq & 1) * 32 + (kq >> 1) * 16) = int4v{(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
                 if (a.y && kq < 3) *reinterpret_cast<float4v*>(a.y + pix * 12 + 4 * kq) = m;      // (tests: the f32 view of the same map)
             };
             if (mono) {
@@ -328,7 +352,7 @@ __global__ __launch_bounds__(256, RPW == 4 ? 3 : 6) void pnet_conv1_kernel(P1Arg
                 // (couts 10..15: zero weights and zero bias -> 0 + (-1) min(0, 0) = 0, as the map wants them)
                 const int odd = li & 1;
                 const int py = ((y0 + wave * RPW) >> 1) + odd;
-#pragma unroll
+#pragma unroll P1_CTU
                 for (int ct = 0; ct < 4; ++ct) {
                     float4v m[2];
 #pragma unroll

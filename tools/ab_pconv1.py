@@ -8,7 +8,7 @@ warnings.simplefilter("ignore")
 app = FaceAnalysis(name="synthetic", arch="r100", cap_o=4).prepare(ctx_id=0)
 frames = bench.synth_frames(64, 1080, 1920, 0, torch.device("cuda:0"))
 for rep in range(3):
-    for pc1 in (False, 25, 40000, 80000, 150000):
+    for pc1 in (False, 20000, 40000, 80000):
         app.det.split_pconv1 = bool(pc1)
         app.det.split_pconv1_min_px = pc1 or 0
         for _ in range(3):
