@@ -314,7 +314,8 @@ __device__ __forceinline__ void pnet_refine_body(const PRefArgs& a, const int bl
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     float* win = wins[wave];
-    if (a.counts[block] == 0) return;                       // block-uniform, before any barrier
+    if (a.counts[block] <= wave * 16) return;               // nothing on the list for this wave (no block-level barrier below): with the
+                                                            // band-only list most blocks keep one wave, and a wave's 107 weight loads stay away
     // ---- weights as A operands: lane (row li, k slot kq)
     float wa2[27], wa3[2][36], hwa[8];
 #pragma unroll
