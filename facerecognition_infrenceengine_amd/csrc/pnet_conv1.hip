@@ -109,8 +109,12 @@ __global__ __launch_bounds__(256, RPW == 4 ? (F16 ? P1_OCC : 3) : 6) void pnet_c
     constexpr int NTAB = IH + P1_IW;
     constexpr int XPX = NPF * 256;            // pixel slots of the LDS tile; F16: per plane (the slack behind NPX is what kh = 3 / kw' = 3 read)
     static_assert(!F16 || XPX >= NPX + P1_IW + 4, "slack behind the tile for the zero-weight taps");
-    __shared__ __attribute__((aligned(16))) float xin[F16 ? XPX * 4 : XPX * 3];      // slots past NPX (the last slot of some threads) land in the padding
-    __shared__ __attribute__((aligned(16))) int4v tab[2][NTAB];
+    // TWO tile buffers when a block walks several tiles: tile i + 1 is blended into the other buffer BEFORE this wave's conv of tile i, so a
+    // tile costs one barrier (two before) and the blend (VALU) of some waves runs under the MFMAs of others
+    constexpr int NXB = RPB > 1 ? 2 : 1, NTB = RPB > 1 ? 3 : 1;
+    constexpr int XFL = F16 ? XPX * 4 : XPX * 3;
+    __shared__ __attribute__((aligned(16))) float xin2[NXB][XFL];                     // slots past NPX (the last slot of some threads) land in the padding
+    __shared__ __attribute__((aligned(16))) int4v tab[NTB][NTAB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float pinf = opaque_inf();
 
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(256, RPW == 4 ? (F16 ? P1_OCC : 3) : 6) void pnet_c
         }
         edge = last || __builtin_amdgcn_ballot_w64(special) != 0;
     };
-    auto store_tile_as = [&](int buf, auto EDGE) __attribute__((always_inline)) {
+    auto store_tile_as = [&](int buf, float* xin, auto EDGE) __attribute__((always_inline)) {
         constexpr bool E = decltype(EDGE)::value;
         float wy[NPF], wx[NPF];
 #pragma unroll
@@ -262,9 +266,9 @@ __global__ __launch_bounds__(256, RPW == 4 ? (F16 ? P1_OCC : 3) : 6) void pnet_c
             }
         }
     };
-    auto store_tile = [&](int buf) __attribute__((always_inline)) {
-        if (edge) store_tile_as(buf, std::true_type{});
-        else store_tile_as(buf, std::false_type{});
+    auto store_tile = [&](int buf, float* xdst) __attribute__((always_inline)) {
+        if (edge) store_tile_as(buf, xdst, std::true_type{});
+        else store_tile_as(buf, xdst, std::false_type{});
     };
 
     float4v bias_r[3], slope_r[3];
@@ -281,9 +285,11 @@ __global__ __launch_bounds__(256, RPW == 4 ? (F16 ? P1_OCC : 3) : 6) void pnet_c
         __syncthreads();
         load_tile(item0, 0);
         if (RPB > 1 && item0 + 1 < nitems) make_tables(item0 + 1, 1);
-        store_tile(0);
+        if (RPB > 2 && item0 + 2 < nitems) make_tables(item0 + 2, 2);
+        store_tile(0, xin2[0]);
     }
     __syncthreads();
+    if (RPB > 1 && item0 + 1 < nitems) load_tile(item0 + 1, 1);        // raw bytes of tile 1: blended at the top of iteration 0
 
     for (int rr = 0; rr < RPB; ++rr) {
         const int item = item0 + rr;
@@ -292,9 +298,14 @@ __global__ __launch_bounds__(256, RPW == 4 ? (F16 ? P1_OCC : 3) : 6) void pnet_c
         const int n = tile_ / per_img, rem = tile_ - n * per_img;
         const int ry = rem / a.regions_x, rx = rem - ry * a.regions_x;
         const int y0 = ry * TH, x0 = rx * P1_TW;
-        const bool more = rr + 1 < RPB && item + 1 < nitems;
-        const int nbuf = (rr + 1) & 1;
-        if (more) load_tile(item + 1, nbuf);             // global loads fly under this tile's MFMAs
+        const float* xin = xin2[rr & (NXB - 1)];
+        if constexpr (RPB > 1) {
+            // tile rr + 1: raw bytes (fetched one iteration ago) -> the other buffer; tile rr + 2: global loads fly under this tile's MFMAs;
+            // tile rr + 3: tables.  Buffers (rr + 1) & 1 / rr % 3 were last read before the barrier that ended iteration rr - 1.
+            if (rr + 1 < RPB && item + 1 < nitems) store_tile((rr + 1) % 3, xin2[(rr + 1) & 1]);
+            if (rr + 2 < RPB && item + 2 < nitems) load_tile(item + 2, (rr + 2) % 3);
+            if (rr + 3 < RPB && item + 3 < nitems) make_tables(item + 3, rr % 3);
+        }
 
         if constexpr (F16) {
             // ---- conv on the f16 matrix cores: the wave's RPW rows x four 16-column tiles; lane (li, kq): pixel column 16 ct + li,
@@ -543,12 +554,7 @@ __global__ __launch_bounds__(256, RPW == 4 ? (F16 ? P1_OCC : 3) : 6) void pnet_c
             }
         }
         }   // !F16
-        if (more) {
-            __syncthreads();                 // every wave is done reading this tile and the tables of the next one's loads
-            store_tile(nbuf);
-            if (rr + 2 < RPB && item + 2 < nitems) make_tables(item + 2, rr & 1);
-            __syncthreads();
-        }
+        if (rr + 1 < RPB && item + 1 < nitems) __syncthreads();      // tile rr + 1 and the tables of tile rr + 3 are in LDS; every wave is done with tile rr
     }
 }
 
