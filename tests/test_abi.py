@@ -56,6 +56,20 @@ def test_invalid_arguments_return_error_not_crash():
         lib.fr_dconv_mfma_f32(99, one, one, one, None, one, 1, 8, 8, None, None, None, 0, 0, None, 0, None, None)
     with pytest.raises(_lib.FrError, match="bad argument"):
         lib.fr_conv_splitk_epilogue(None, 2, 10, 64, 7, 7, None, 0, None, None, None, None)
+    # round-4 entries of the batch detector: argument checks come before any launch
+    import ctypes as C
+    one = C.c_void_p(16)
+    with pytest.raises(_lib.FrError, match="mode must be 0 or 1"):
+        lib.fr_pnet_conv1_band(2, one, 1, 64, 64, 32, 32, one, one, one, None, one, None, None, 0, None)
+    with pytest.raises(_lib.FrError, match="mode 0 writes the split map"):
+        lib.fr_pnet_conv1_band(0, one, 1, 64, 64, 32, 32, one, one, one, None, None, None, None, 0, None)
+    with pytest.raises(_lib.FrError, match="mode 1 needs the f32 map and a tile list"):
+        lib.fr_pnet_conv1_band(1, one, 1, 64, 64, 32, 32, one, one, one, one, None, None, None, 0, None)
+    with pytest.raises(_lib.FrError, match="bad argument"):
+        lib.fr_pnet_conv1_band(0, one, 1, 64, 64, 2, 32, one, one, one, None, one, None, None, 0, None)      # a level below 3 rows
+    with pytest.raises(_lib.FrError, match="bad argument"):
+        lib.fr_pnet_band_tiles(one, 1, 4, 40, one, one, None)                                                  # a conv1 map below 5 x 5
+    assert lib.fr_pnet_band_tiles_count(0, 10, 10) == 0 and lib.fr_pnet_band_tiles_count(2, 17, 70) == 2 * 3 * 3
 
 
 def test_call_list_entry_layout_and_slots():
