@@ -226,6 +226,7 @@ def main():
     ap.add_argument("--prio", default="none", choices=["none", "det", "emb"], help="stream given high priority")
     ap.add_argument("--one-stream", action="store_true", help="detector and embedder on one stream (no overlap)")
     ap.add_argument("--det-sides", type=int, default=None, help="A/B: side streams the detector deals pyramid levels 1.. over")
+    ap.add_argument("--embed-chunk", type=int, default=None, help="A/B: faces per embed forward (IResNetHIP.max_chunk; default 256)")
     ap.add_argument("--det-level-nms", default=None, choices=["merged", "per-level"], help="A/B: per-level NMS as one launch or one per level")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -332,6 +333,8 @@ def main():
     app.det.one_stream = args.one_stream        # profiling: pyramid levels on one stream too, per-kernel durations add up
     if args.det_sides is not None:
         app.det.level_streams = args.det_sides
+    if args.embed_chunk is not None:
+        app.rec.max_chunk = args.embed_chunk
     if args.det_level_nms is not None:
         app.det.merged_level_nms = args.det_level_nms == "merged"
     if args.pipes <= 0:
