@@ -90,8 +90,8 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
         }
         *reinterpret_cast<half8*>(wf + (size_t)e * 16) = o;
     }
-    for (int e = tid; e < 16; e += P23_NT) { cst[e] = a.b2[e]; cst[16 + e] = a.s2[e]; }
-    for (int e = tid; e < 32; e += P23_NT) { cst[32 + e] = a.b3[e]; cst[64 + e] = a.s3[e]; }
+    for (int e = tid; e < 16; e += P23_NT) { cst[e] = a.b2[e]; cst[16 + e] = a.s2[e] - 1.f; }      // slopes as s - 1: PReLU = x + (s - 1) min(x, 0), two operations
+    for (int e = tid; e < 32; e += P23_NT) { cst[32 + e] = a.b3[e]; cst[64 + e] = a.s3[e] - 1.f; }
     for (int e = tid; e < 8; e += P23_NT) cst[96 + e] = e < 6 ? a.hb[e] : 0.f;
     if (tid == 0) *lcnt = 0;
     int* const seg = a.list + (size_t)blockIdx.x * a.seg_cap;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
                 if (t < nt && q < P23_X2PX) {
                     float4v v = acc[t] + bb;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * ss[e];
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(fminf(v[e], 0.f), ss[e], v[e]);
                     half4 hi, lo;
                     p23_split4(v, hi, lo);
                     char* o = x2t + q * 32 + fq * 8;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(P23_NT, 4) void pnet23_split_f16(P23Args a) {
                 half8 bh, bl;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float x0 = v0[e] > 0.f ? v0[e] : v0[e] * s30[e], x1 = v1[e] > 0.f ? v1[e] : v1[e] * s31[e];
+                    const float x0 = __builtin_fmaf(fminf(v0[e], 0.f), s30[e], v0[e]), x1 = __builtin_fmaf(fminf(v1[e], 0.f), s31[e], v1[e]);
                     const half_t h0 = (half_t)x0, h1 = (half_t)x1;
                     bh[e] = h0; bl[e] = (half_t)(x0 - (float)h0);
                     bh[4 + e] = h1; bl[4 + e] = (half_t)(x1 - (float)h1);
