@@ -28,6 +28,9 @@ sys.path.insert(0, ROOT)
 # another box: 16 queues 13.16 / 13.01 / 13.19, 24 queues 13.04 / 13.00 / 12.87, 32 queues 12.99 -> 24.
 # Must be set before the runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle: invalid argument otherwise); the launcher's
+# environment normally carries it already
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
