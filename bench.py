@@ -56,7 +56,7 @@ def synth_frames(n, h, w, seed, device):
     return (img.permute(0, 2, 3, 1).clamp(0, 1) * 255).round().to(torch.uint8).contiguous()
 
 
-def cpu_baseline(frames, gallery, threads=None, match_memo=None):
+def cpu_baseline(frames, gallery, threads=None, match_memo=None, warmups=0, reps=1):
     """CPU oracle on a bounded sample of the same workload (rank 0, N == 1 only): ``frames`` (list of uint8 HWC BGR
     arrays - copies of the first frames of the GPU's batch 0) through oracle detect -> align -> r100 fp32 -> the
     literal per-row Python match loop over ``gallery`` (ordered dict str(row) -> f32[512]: the rows the GPU scans, keyed
@@ -64,6 +64,8 @@ def cpu_baseline(frames, gallery, threads=None, match_memo=None):
     all host cores).  ``match_memo`` (a dict shared by the calls of a thread sweep): the match loop is single-threaded
     Python whatever ``threads`` is, so it runs - and is timed - in the FIRST call only; later calls add that time to their
     own detect + embed time and take its ids (a 1.25 M-row gallery is millions of interpreter iterations per face).
+    ``warmups`` / ``reps``: untimed passes, then the MEDIAN of ``reps`` timed passes (SURVEY.md 8(d) for C1: 3 and 20; the C2
+    sample is ~10 - 30 s of CPU work per pass and is timed once).
     Returns (record, per-frame results)."""
     from facerecognition_infrenceengine_amd import weights
     from oracle import align as oalign, detect as odetect, match as omatch, nets as onets
@@ -74,40 +76,50 @@ def cpu_baseline(frames, gallery, threads=None, match_memo=None):
     p, r, o = weights.synth_mtcnn_states()
     st = weights.synth_iresnet_state("r100")
     memo = match_memo if match_memo is not None else {}
-    reuse = "match" in memo
-    t0 = time.perf_counter()
-    faces, results, t_match = 0, [], 0.0
-    for fi, fr in enumerate(frames):
-        b, s, k = odetect.detect(fr, p, r, o, cap_o=FACES_PER_FRAME)
-        rec = {"bbox": b, "score": s, "kps": k, "emb": np.zeros((0, 512), np.float32), "ids": [], "dec": []}
-        if len(s):
-            crops = [oalign.norm_crop(fr, kk)[0] for kk in k]
-            x = torch.from_numpy(np.stack([oalign.crop_to_net(c) for c in crops]))
-            rec["emb"] = onets.iresnet_forward(st, x, weights.IRESNET_LAYERS["r100"]).numpy()
-            if reuse and len(memo["match"][fi][0]) == len(s):
-                rec["ids"], rec["dec"] = memo["match"][fi]
+    frame_memo = memo.setdefault("frames", {})        # frame index -> (ids, decisions, seconds the literal loop took for them)
+
+    def one_pass(use_memo):
+        t0 = time.perf_counter()
+        faces, results, t_match, t_reused = 0, [], 0.0, 0.0
+        for fi, fr in enumerate(frames):
+            b, s, k = odetect.detect(fr, p, r, o, cap_o=FACES_PER_FRAME)
+            rec = {"bbox": b, "score": s, "kps": k, "emb": np.zeros((0, 512), np.float32), "ids": [], "dec": []}
+            if len(s):
+                crops = [oalign.norm_crop(fr, kk)[0] for kk in k]
+                x = torch.from_numpy(np.stack([oalign.crop_to_net(c) for c in crops]))
+                rec["emb"] = onets.iresnet_forward(st, x, weights.IRESNET_LAYERS["r100"]).numpy()
+                hit = frame_memo.get(fi) if use_memo else None
+                if hit is not None and len(hit[0]) == len(s):
+                    rec["ids"], rec["dec"] = hit[0], hit[1]
+                    t_reused += hit[2]              # only the frames whose loop really was skipped add their recorded time
+                else:
+                    tm = time.perf_counter()
+                    for e in rec["emb"]:
+                        q = omatch.renormalise(e / np.linalg.norm(e))
+                        bid, bs = omatch.linear_scan(q, gallery)                 # literal per-row Python loop
+                        rec["ids"].append(-1 if bid is None else int(bid))
+                        rec["dec"].append(omatch.decide_live(bid, bs)[0] is not None)
+                    tf = time.perf_counter() - tm
+                    t_match += tf
+                    if use_memo:
+                        frame_memo[fi] = (rec["ids"], rec["dec"], tf)
                 faces += len(s)
-            else:
-                tm = time.perf_counter()
-                for e in rec["emb"]:
-                    q = omatch.renormalise(e / np.linalg.norm(e))
-                    bid, bs = omatch.linear_scan(q, gallery)                 # literal per-row Python loop
-                    rec["ids"].append(-1 if bid is None else int(bid))
-                    rec["dec"].append(omatch.decide_live(bid, bs)[0] is not None)
-                    faces += 1
-                t_match += time.perf_counter() - tm
-        results.append(rec)
-    dt = time.perf_counter() - t0
-    if reuse:
-        dt += memo["t_match"]
-    else:
-        memo["match"], memo["t_match"] = [(r_["ids"], r_["dec"]) for r_ in results], t_match
+            results.append(rec)
+        return time.perf_counter() - t0 + t_reused, faces, results, t_match + t_reused, t_reused > 0
+
+    for _ in range(warmups):
+        one_pass(False)
+    passes = [one_pass(reps == 1) for _ in range(max(reps, 1))]
+    passes.sort(key=lambda t: t[0])
+    dt, faces, results, t_match, reused = passes[len(passes) // 2]
     torch.set_num_threads(default_threads)
-    how = ", as timed in the first run of the sweep" if reuse else ""
+    how = ", partly as timed in an earlier run of the sweep" if reused else ""
+    rep_note = f"median of {reps} passes after {warmups} warm-up passes, " if reps > 1 else ""
     return {"value": round(faces / dt, 3), "unit": "faces/s", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "port",
+            "ms_per_pass": round(dt * 1e3, 2),
             "sample": f"{len(frames)} synthetic {H}x{W} frames (the first frames of the GPU's batch 0), {faces} faces, r100 "
                       f"fp32 torch-CPU + literal {len(gallery)}-row Python match loop "
-                      f"({memo['t_match']:.1f} s, single-threaded{how}), {dt:.1f} s"}, results
+                      f"({t_match:.3f} s, single-threaded{how}), {rep_note}{dt:.2f} s"}, results
 
 
 def oracle_check(results, gpu, cos_tol):
@@ -194,6 +206,29 @@ def self_launch(n):
     sys.exit(subprocess.run(cmd).returncode)
 
 
+def ranks_sharing_a_device(ranks_rec):
+    """[(rank, rank)] pairs of a gathered ``ranks`` record that report the same device (PCI address, else uuid, else index)"""
+    seen, clash = {}, []
+    for d in ranks_rec:
+        key = d.get("pci_bus_id") or d.get("uuid") or ("index", d["device_index"])
+        if key in seen:
+            clash.append((seen[key], d["rank"]))
+        seen.setdefault(key, d["rank"])
+    return clash
+
+
+def rank_identity(device):
+    """What proves that a rank sat on a device of its own: the HIP device index it used, the PCI address and the uuid of that
+    device (torch's device properties; a field this torch build does not carry is left out)."""
+    pr = torch.cuda.get_device_properties(device)
+    out = {"device_index": device.index, "name": pr.name}
+    if all(hasattr(pr, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        out["pci_bus_id"] = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+    if hasattr(pr, "uuid"):
+        out["uuid"] = str(pr.uuid)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -203,6 +238,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU oracle leg (timed at each thread count)")
     ap.add_argument("--cpu-threads", default="1,16,0", help="torch thread counts of the CPU leg (0 = all host cores); the "
                                                              "best is reported as cpu_baseline, all of them in cpu_baseline_sweep")
+    ap.add_argument("--cpu-reps", type=int, default=0, help="timed passes of the CPU leg per thread count, the median is reported "
+                                                            "(default: 20 after 3 warm-up passes for C1 - SURVEY.md 8(d) - and 1 otherwise)")
     ap.add_argument("--no-side", action="store_true", help="skip the side measurements (value_pcie, latency_c1_ms)")
     ap.add_argument("--depth", type=int, default=3, help="steps in flight before the oldest one's ids are fetched")
     ap.add_argument("--ingest", default="resident", choices=["resident", "pinned"],
@@ -226,7 +263,10 @@ def main():
                          "streams): C2 2x1 23 400 faces/s, 1x1 24 150, 1x2 25 400, 2x2 24 000; C5 25 500 / 25 470 / 27 070 / 25 060; "
                          "C3 20 780 / 18 800 / 18 340 / 20 880 - with one pair the one-workgroup-per-CU stage kernels of step i find the "
                          "CUs free of step i + 2's detector blocks")
-    ap.add_argument("--prio", default="none", choices=["none", "det", "emb"], help="stream given high priority")
+    ap.add_argument("--embed-group", type=int, default=0,
+                    help="consecutive steps whose face slots share ONE embed forward (FaceAnalysis.detect_embed_slots(crops_out=...) + "
+                         "embed_slots).  Default: 2 for C3 - a step is 8 x 4K frames x 16 slots = 128 faces, half of the 256 CUs for the "
+                         "one-workgroup-per-face stage kernels; two steps' crops side by side fill them - and 1 otherwise")
     ap.add_argument("--one-stream", action="store_true", help="detector and embedder on one stream (no overlap)")
     ap.add_argument("--det-sides", type=int, default=None, help="A/B: side streams the detector deals pyramid levels 1.. over")
     ap.add_argument("--embed-chunk", type=int, default=None, help="A/B: faces per embed forward (IResNetHIP.max_chunk; default 256)")
@@ -326,7 +366,7 @@ def main():
     ingest = None
     if args.ingest == "pinned":
         from facerecognition_infrenceengine_amd.ingest import FrameIngest
-        ingest = FrameIngest(FRAMES, H, W, device, depth=args.depth + 1 + args.ingest_ahead, chunks=args.ingest_chunks, streams=args.ingest_streams)
+        ingest = FrameIngest(FRAMES, H, W, device, depth=args.depth + max(args.embed_group, 1) + args.ingest_ahead, chunks=args.ingest_chunks, streams=args.ingest_streams)
         for k in range(ingest.depth):       # what the capture side would have written
             ingest.host_buffer(k)[...] = batches[k % nbatch].cpu().numpy()
 
@@ -342,62 +382,93 @@ def main():
         app.det.merged_level_nms = args.det_level_nms == "merged"
     if args.pipes <= 0:
         args.pipes = 1 if FRAMES >= 16 else 2
+    if args.embed_group <= 0:
+        args.embed_group = 2 if (args.workload == "C3" and two) else 1
+    G = args.embed_group
     pipes = []
     for _ in range(args.pipes if two else 1):
-        pipes.append((torch.cuda.Stream(device=device, priority=-1 if args.prio == "det" else 0) if two else None,
-                      torch.cuda.Stream(device=device, priority=-1 if args.prio == "emb" else 0) if two
-                      else torch.cuda.current_stream(device)))
+        pipes.append((torch.cuda.Stream(device=device) if two else None,
+                      torch.cuda.Stream(device=device) if two else torch.cuda.current_stream(device)))
 
     # ids leave the device through pinned host buffers + an event: a pageable .cpu() drains both streams
     q_rows = FRAMES * FACES_PER_FRAME
     pinned = [{"idx": torch.empty(q_rows, dtype=torch.int64).pin_memory(),
                "dec": torch.empty(q_rows, dtype=torch.int32).pin_memory(),
-               "counts": torch.empty(FRAMES, dtype=torch.int32).pin_memory()} for _ in range(args.depth)]
+               "counts": torch.empty(FRAMES, dtype=torch.int32).pin_memory()} for _ in range(args.depth + G)]
+    # embed groups (G > 1): the aligned crops of G consecutive steps side by side, one buffer per stream pair (a pair's launches
+    # are ordered: the next group's warps come behind this group's embed forward)
+    group_crops = [torch.empty((G * q_rows, 112, 112, 8), dtype=torch.float16, device=device) for _ in pipes] if G > 1 else None
 
     def run_loop(ingest, steps, warmup):
         """warmup untimed steps, then `steps` timed steps bracketed by barrier + synchronize on both sides.
-        Returns (seconds, faces, batch latencies ms, per-step (idx, dec, counts) host copies)."""
+        Returns (seconds, faces, batch latencies ms, per-step (idx, dec, counts, source batch) host copies).  Steps are numbered
+        0 .. warmup + steps - 1 across both phases (ring slots, pinned buffers and stream pairs follow that number)."""
         batch_ms, results = [], []
         uploads = {}
+        total = warmup + steps
+        group = []                          # embed groups: the steps whose crops wait for their shared forward
 
-        def enqueue(i):
+        def source(i):
+            return (i % ingest.depth) % nbatch if ingest is not None else i % nbatch
+
+        def finish(i, host, r, emb_rows, s_emb, t_in):
+            """match + decision + asynchronous copies of one step's ids to pinned host memory; the step's pending entry"""
+            idx, score = sharded.match(emb_rows)
+            dec = gm.decide_device(idx, score, 0.4)
+            host["idx"].copy_(idx.to(torch.int64), non_blocking=True)
+            host["dec"].copy_(dec.to(torch.int32), non_blocking=True)
+            host["counts"].copy_(r["counts"], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(s_emb)
+            return host, ev, (idx, dec, r, s_emb), t_in, source(i)
+
+        def enqueue(i, flush):
             """One step, enqueued without any host synchronisation: fixed per-frame face slots, device-side counts,
-            asynchronous copy of the ids / decisions / counts to pinned host memory."""
+            asynchronous copy of the ids / decisions / counts to pinned host memory.  Returns the pending entries that became
+            complete with this step (one; with embed groups none, or the whole group's)."""
             t_in = time.perf_counter()
-            host = pinned[i % args.depth]
-            s_det, s_emb = pipes[i % len(pipes)]
+            host = pinned[i % len(pinned)]
+            pi = (i // G) % len(pipes)
+            s_det, s_emb = pipes[pi]
             with torch.cuda.stream(s_emb):
+                kw = {}
+                if G > 1:
+                    kw["crops_out"] = group_crops[pi][len(group) * q_rows:(len(group) + 1) * q_rows]
                 if ingest is not None:          # PCIe-inclusive variant: pinned host ring -> device on a copy stream
-                    for j in range(i, i + 1 + args.ingest_ahead):
+                    for j in range(i, min(i + 1 + args.ingest_ahead, total)):      # never past the loop's last step
                         if j not in uploads:
                             uploads[j] = ingest.upload(j)
                     frames, ready = uploads.pop(i)
-                    r = app.detect_embed_slots(frames, det_stream=s_det, ready_event=ready)
+                    r = app.detect_embed_slots(frames, det_stream=s_det, ready_event=ready, **kw)
                     ingest.release(i)           # the warp (last reader of the frames) is queued on this stream by now
                 else:
-                    r = app.detect_embed_slots(batches[i % nbatch], det_stream=s_det)
-                idx, score = sharded.match(r["normed_embedding"])
-                dec = gm.decide_device(idx, score, 0.4)
-                host["idx"].copy_(idx.to(torch.int64), non_blocking=True)
-                host["dec"].copy_(dec.to(torch.int32), non_blocking=True)
-                host["counts"].copy_(r["counts"], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(s_emb)
-            return host, ev, (idx, dec, r, s_emb), t_in
+                    r = app.detect_embed_slots(batches[i % nbatch], det_stream=s_det, **kw)
+                if G == 1:
+                    return [finish(i, host, r, r["normed_embedding"], s_emb, t_in)]
+                group.append((i, host, r, t_in))
+                if len(group) < G and not flush:
+                    return []
+                _, normed = app.embed_slots(group_crops[pi][:len(group) * q_rows])
+                done = [finish(gi, gh, gr, normed[k * q_rows:(k + 1) * q_rows], s_emb, gt) for k, (gi, gh, gr, gt) in enumerate(group)]
+                group.clear()
+                return done
 
         def fetch(pending):
             """ids on the host = end of the step; faces = detected faces (slots beyond a frame's count are ignored)."""
-            host, ev, _keep, t_in = pending
+            host, ev, _keep, t_in, src = pending
             ev.synchronize()
             batch_ms.append((time.perf_counter() - t_in) * 1e3)      # frames handed over -> ids on the host
-            results.append((host["idx"].clone(), host["dec"].clone(), host["counts"].clone()))   # 3 KB, for the self-check
+            results.append((host["idx"].clone(), host["dec"].clone(), host["counts"].clone(), src))   # 3 KB, for the self-check
             return int(host["counts"].sum())
 
-        def step(i, pending):
+        def step(i, pending, flush):
             """Software pipeline of depth args.depth: step i is enqueued before step i-depth+1's ids are pulled to the
             host, so neither HIP stream waits for the Python driver between steps."""
-            pending.append(enqueue(i))
-            return fetch(pending.popleft()) if len(pending) >= args.depth else 0
+            pending.extend(enqueue(i, flush))
+            n = 0
+            while len(pending) >= args.depth + (G - 1):
+                n += fetch(pending.popleft())
+            return n
 
         def drain(pending):
             n = 0
@@ -407,14 +478,14 @@ def main():
 
         pending = deque()
         for i in range(warmup):
-            step(i, pending)
+            step(i, pending, i == warmup - 1)
         drain(pending)
         sync()
         t0 = time.perf_counter()
         faces = 0
         batch_ms.clear(); results.clear()
-        for i in range(steps):
-            faces += step(i, pending)
+        for i in range(warmup, total):
+            faces += step(i, pending, i == total - 1)
         faces += drain(pending)                    # all K steps' ids are on the host inside the timed region
         sync()
         return time.perf_counter() - t0, faces, batch_ms, results
@@ -438,8 +509,7 @@ def main():
     expect = {}
     bad_step = -1
     plant_hit = plant_all = 0
-    for k, (idx_h, dec_h, cnt_h) in enumerate(results):
-        src = (k % ingest.depth) % nbatch if ingest is not None else k % nbatch      # the batch step k used
+    for k, (idx_h, dec_h, cnt_h, src) in enumerate(results):            # src: the batch step k used
         if src not in expect:
             r = app.detect_embed_slots(batches[src])
             idx2, score2 = sharded.match(r["normed_embedding"])
@@ -554,16 +624,52 @@ def main():
         side["latency_c1_ms"] = c1_latency(app, device)      # (before the pinned ring below: 2.4 GB of page-locked host memory)
         if args.ingest == "resident":           # PCIe-inclusive rate: every step's 398 MB cross PCIe from a pinned ring
             from facerecognition_infrenceengine_amd.ingest import FrameIngest
-            ing = FrameIngest(FRAMES, H, W, device, depth=args.depth + 1 + args.ingest_ahead)
+            ing = FrameIngest(FRAMES, H, W, device, depth=args.depth + G + args.ingest_ahead)
             for k in range(ing.depth):
                 ing.host_buffer(k)[...] = batches[k % nbatch].cpu().numpy()
+            # the link alone: ONE step's frames (pinned) -> device, nothing else running - what value_pcie / value is to be read against
+            torch.cuda.synchronize()
+            ce = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            dst = torch.empty_like(batches[0])
+            src_t = ing._host[0]                    # slot 0's page-locked buffer
+            dst.copy_(src_t, non_blocking=True)
+            ce[0].record()
+            for _ in range(5):
+                dst.copy_(src_t, non_blocking=True)
+            ce[1].record()
+            torch.cuda.synchronize()
+            copy_ms = ce[0].elapsed_time(ce[1]) / 5
+            step_bytes = FRAMES * H * W * 3
+            side["pcie"] = {"bytes_per_step": step_bytes, "copy_alone_ms": round(copy_ms, 3),
+                            "copy_alone_gbps": round(step_bytes / copy_ms / 1e6, 2),
+                            "floor_ms": round(copy_ms, 3),
+                            "floor_faces_per_s": round(faces / args.steps / copy_ms * 1e3, 1),
+                            "pinned": bool(src_t.is_pinned()),
+                            "note": "one step's frames, pinned host memory -> HBM, timed alone with HIP events (median-free mean of 5); "
+                                    "floor_* = the step time / rate at which the link alone would bound the PCIe-inclusive pipeline"}
+            del dst
             n_p = max(6, min(args.steps, 40))            # as many steps as the headline loop: the pipeline fill is a fixed cost
             dt_p, faces_p, _, _ = run_loop(ing, n_p, 4)
             side["value_pcie"] = round(faces_p / dt_p, 1)
+            side["pcie"]["ms_per_step_pcie"] = round(dt_p / n_p * 1e3, 3)
+            side["pcie"]["link_busy_frac"] = round(copy_ms / (dt_p / n_p * 1e3), 3)
             side["value_pcie_note"] = (f"{n_p} steps, frames uploaded from pinned host memory on a copy stream every step, each upload issued "
                                        f"{args.ingest_ahead} steps ahead of its step")
             del ing
 
+    # ---- who ran where (N > 1 / the one-rank rehearsal): every rank's device index, PCI address, uuid; two ranks on one device fail
+    ranks_rec = None
+    if world > 1 or args.force_exchange:
+        mine = {"rank": rank, "local_rank": local_rank, **rank_identity(device)}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        ranks_rec = sorted(gathered, key=lambda d: d["rank"])
+        clash = ranks_sharing_a_device(ranks_rec)
+        if clash and not args.same_device:
+            if rank == 0:
+                print(f"ranks share a device {clash}: {ranks_rec}", file=sys.stderr, flush=True)
+            dist.destroy_process_group()
+            sys.exit(5)
     if rank == 0:
         out = {"metric": f"faces/sec end-to-end @{H}p", "value": round(faces / dt, 1), "unit": "faces/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -573,6 +679,7 @@ def main():
                                       f"512/64/{FACES_PER_FRAME}), ArcFace r100 {'fp8 body convs' if args.workload == 'C5' else 'f16'} embed, {GALLERY_ROWS}-row cosine "
                                       "gallery (row-sharded over ranks)",
                           "frames_per_step_per_gpu": FRAMES, "ingest": args.ingest, "faces_per_step": faces / args.steps,
+                          "steps_per_embed_forward": G,
                           "gallery_rows": GALLERY_ROWS, "gallery_scan": args.gallery, "weights": "seeded synthetic",
                           "parallelism": f"frame-shard x{world} + gallery row-shard"},
                # amortised: wall time / faces.  Batch latency: frames handed to the pipeline -> that batch's ids on the
@@ -582,7 +689,8 @@ def main():
                "p50_batch_latency_ms": round(float(np.percentile(batch_ms, 50)), 3),
                "p95_batch_latency_ms": round(float(np.percentile(batch_ms, 95)), 3),
                "p50_face_latency_ms": round(float(np.percentile(batch_ms, 50)) / max(faces / world / args.steps, 1), 4),
-               "stage_ms_alone": stage_ms, **({"exchange_ms": exchange_ms} if exchange_ms is not None else {}), **side,
+               "stage_ms_alone": stage_ms, **({"exchange_ms": exchange_ms} if exchange_ms is not None else {}),
+               **({"ranks": ranks_rec, "ranks_distinct_devices": not args.same_device} if ranks_rec is not None else {}), **side,
                "self_check": f"all {len(results)} timed steps == sequential single-stream re-run (ids, decisions, counts)",
                "planted_top1": {"faces": plant_all, "matched_own_row": plant_hit,
                                 "note": "timed faces whose top-1 id is the gallery row planted for them (embedding + "
@@ -599,12 +707,14 @@ def main():
             G_h = gm.G.cpu().numpy()
             gallery = {str(i): G_h[i] for i in range(G_h.shape[0])}
             sweep, res0, memo = [], None, {}
+            c1 = args.workload == "C1"          # C1 exactly - warm-up 3, median of 20, at 1 thread and at all cores
             for t in [int(v) for v in args.cpu_threads.split(",") if v.strip() != ""]:
-                rec, res = cpu_baseline(frames_h, gallery, threads=t or None, match_memo=memo)
+                reps = args.cpu_reps if args.cpu_reps > 0 else (20 if c1 else 1)
+                rec, res = cpu_baseline(frames_h, gallery, threads=t or None, match_memo=memo, warmups=3 if (c1 and reps > 1) else 0, reps=reps)
                 sweep.append(rec)
                 res0 = res0 or res
             out["cpu_baseline"] = max(sweep, key=lambda r: r["value"])
-            out["cpu_baseline_sweep"] = [{"cores": r["cores"], "value": r["value"]} for r in sweep]
+            out["cpu_baseline_sweep"] = [{"cores": r["cores"], "value": r["value"], "ms_per_pass": r["ms_per_pass"]} for r in sweep]
             out["oracle_check"] = oracle_check(res0, gpu0, 1e-3)
             if not out["oracle_check"]["ok"]:
                 fail = "oracle_check failed: the GPU's results for batch 0 differ from the CPU oracle's"

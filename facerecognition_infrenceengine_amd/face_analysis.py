@@ -187,7 +187,7 @@ class FaceAnalysis:
         out["embedding"], out["normed_embedding"] = emb, normed
         return out
 
-    def detect_embed_slots(self, frames, det_stream=None, ready_event=None, compact_embed=False):
+    def detect_embed_slots(self, frames, det_stream=None, ready_event=None, compact_embed=False, crops_out=None):
         """Sync-free form for streaming/serving: every frame owns ``cap_o`` face slots.
 
         frames: uint8 [N,H,W,3] BGR on the device.  Returns device tensors only (no host sync):
@@ -203,7 +203,10 @@ class FaceAnalysis:
 
         compact_embed: embed only the slots that hold a face (ONE host sync on the face counts after the detector),
         the outputs keep the slot layout.  For callers that read the results on the host anyway (the camera batcher):
-        8 cameras x 16 slots with a face or two each would otherwise pay for 128 embeddings."""
+        8 cameras x 16 slots with a face or two each would otherwise pay for 128 embeddings.
+
+        crops_out: f16 [N*cap,112,112,8] (a slice of a larger buffer): detect + align only - the aligned crops land there, the
+        returned dict holds the detector outputs, and the caller runs ``embed_slots`` over the whole buffer."""
         if self.det is None:
             raise _lib.FrError("FaceAnalysis.prepare() has not been called")
         N, H, W, _ = frames.shape
@@ -242,12 +245,26 @@ class FaceAnalysis:
             return {"counts": counts, "bbox": boxes, "kps": kps, "det_score": scores, "embedding": emb,
                     "normed_embedding": normed}
         with torch.cuda.device(self.device):
-            crops = torch.empty((N * cap, 112, 112, 8), dtype=torch.float16, device=self.device)
+            if crops_out is not None:                  # the caller embeds several calls' slots in ONE forward (embed_slots)
+                assert crops_out.shape == (N * cap, 112, 112, 8) and crops_out.dtype == torch.float16 and crops_out.is_contiguous()
+            crops = crops_out if crops_out is not None else torch.empty((N * cap, 112, 112, 8), dtype=torch.float16, device=self.device)
             self.lib.fr_warp_affine_5pt_slots(_lib.ptr(frames), N, H, W, _lib.ptr(kps), _lib.ptr(counts), cap, 112,
                                               _lib.ptr(crops), _lib.stream_ptr())
+            if crops_out is not None:
+                return {"counts": counts, "bbox": boxes, "kps": kps, "det_score": scores}
             emb, normed = self.rec.forward(crops)
         return {"counts": counts, "bbox": boxes, "kps": kps, "det_score": scores, "embedding": emb,
                 "normed_embedding": normed}
+
+    def embed_slots(self, crops):
+        """Second half of ``detect_embed_slots(..., crops_out=...)``: ONE embed forward over the aligned crops of several
+        detector calls (f16 [S,112,112,8], slot-major as those calls filled it) -> (embedding, normed_embedding) f32 [S,512].
+        A 4K camera group of 8 frames x 16 slots is 128 faces - half of the 256 CUs for the one-workgroup-per-face stage
+        kernels; two groups' crops side by side fill them (bench.py --workload C3)."""
+        if self.rec is None:
+            raise _lib.FrError("FaceAnalysis.prepare() has not been called")
+        with torch.cuda.device(self.device):
+            return self.rec.forward(crops)
 
     # ------------------------------------------------------------------ HIP-graph replay of the launch sequence
     def enable_graphs(self, on=True):

@@ -7,6 +7,7 @@ ordering, thresholds, capacities) are those written down in ``oracle/detect.py``
 """
 import contextlib
 import ctypes
+import logging
 import math
 import threading
 
@@ -127,7 +128,7 @@ class MTCNNHIP:
     SINGLE_FRAME_LEVEL_STREAMS = 4
     def __init__(self, pstate, rstate, ostate, device="cuda:0", minsize=20, factor=0.709,
                  thresholds=(0.6, 0.7, 0.7), cap_scale=2048, keep_scale=256, cap_p=512, cap_r=64, cap_o=16,
-                 fused_pnet=True):
+                 fused_pnet=True, batch_min_pixels=None):
         _lib.require_gpu()
         self.lib = _lib.load()
         self.device = torch.device(device)
@@ -141,6 +142,14 @@ class MTCNNHIP:
         self.single_frame_level_streams = self.SINGLE_FRAME_LEVEL_STREAMS      # the same for batches of < 8 frames (0: as level_streams)
         self.phase_marks = None            # tools: a list -> (name, event on the caller's stream) at the cascade's phase ends
         self.merged_level_nms = True       # the per-level NMS of ALL levels as one launch behind the pyramid (False: one per level)
+        # From this many PIXELS per call (frames x H x W) the BATCH arithmetic runs: the band-only exact P-Net pass, P-Net conv1 /
+        # R-Net / O-Net on the f16 matrix cores with split-precision operands + exact f32 passes at the thresholds.  Below it the
+        # all-f32 detector (and, under ``solo_max_frames`` + 1 frames, its recorded call list).  The batch path's extra launches (tile
+        # lists, exact chains) cost a fixed ~0.4 ms: measured crossover on MI355X between 8 and 12 x 1080p frames (8: 1.71 against
+        # 1.51 ms, 12: 1.80 / 1.90, 16: 1.93 / 2.18, 32: 2.88 / 3.56; profiles/r05_detector_crossover.txt, tools/crossover_det.py),
+        # i.e. ~ 22 Mpixel - 8 x 4K frames (66 Mpx) are far on the batch side, 8 x 1080p (16.6 Mpx) are not.
+        self.batch_min_pixels = 22_000_000 if batch_min_pixels is None else int(batch_min_pixels)
+        self.solo_max_frames = 7            # up to this many frames a call that is not a batch runs on ONE stream, eagerly, and is recorded
         d = self.device
         p, r, o = ({k: v.detach().float().cpu() for k, v in s.items()} for s in (pstate, rstate, ostate))
         self.p1 = _MConv(0, p["conv1.weight"], p["conv1.bias"], p["prelu1.weight"], d)
@@ -162,12 +171,10 @@ class MTCNNHIP:
         self.pnet_band = True
         self.split_pconv1 = True            # with pnet_band: conv1 on the f16 matrix cores too; the exact pass gets an exact f32 map
                                             # under its cells' windows from the f32 conv1 kernel run over just those tiles
-        self.split_pconv1_min_px = 80000    # ... on levels whose conv1 map has at least this many pixels (the level pays four more
-                                            # small launches for it: worth it on the two largest levels of a 1080p pyramid)
-        # exact pass + candidates of ALL levels in three launches behind the pyramid (fr_pnet_finish_levels) instead of three per
-        # level.  Measured (64 x 1080p, same box): 5.92 - 5.95 ms against 5.77 - 5.80 per level - the per-level launches ride on
-        # their level's stream under the other levels' kernels, the merged ones come behind the join.  Off; kept as an option.
-        self.finish_levels = False
+        self.split_pconv1_min_px = 100000   # ... on levels whose conv1 map has at least this many pixels (the level pays four more
+                                            # small launches for it.  64 x 1080p, detector alone, by the number of levels that take it:
+                                            # 0: 4.74 ms, 1: 4.65, 2: 4.68, 3: 4.71, 4: 4.75, 6: 4.91, all 12: 5.26 - level 0 of a 1080p
+                                            # pyramid (186 k pixels), levels 0 - 2 of a 4K one; profiles/r05_detector_crossover.txt)
         self.refined_cells = None           # optional device int32[1]: cells re-evaluated exactly (diagnostics)
         self.p23_all_heads = False          # True: the fused kernel also writes the approximate heads of the cells it rules out
         self.use_sequence = True            # eager single-frame calls of a known frame shape replay a recorded C call list (fr_detect_sequence)
@@ -219,6 +226,15 @@ class MTCNNHIP:
             self._gemm[lid] = (packed, b.to(torch.float32).contiguous().to(d), sl.to(torch.float32).contiguous().to(d))
         self.o6 = _MConv(25, torch.cat([o["dense6_1.weight"], o["dense6_2.weight"], o["dense6_3.weight"]]).reshape(16, 256, 1, 1),
                          torch.cat([o["dense6_1.bias"], o["dense6_2.bias"], o["dense6_3.bias"]]), None, d)
+
+    def set_exact(self, on=True):
+        """All-exact switch of the batch path: with ``on`` every value a kept candidate carries - P-Net cell scores / regressions,
+        R-/O-Net heads - is the all-f32 kernels', bit for bit (pnet_band and split_ro off: the exact P-Net pass re-evaluates every
+        cell that can be kept, R-/O-Net run their f32 layers), so that NMS ORDER, box truncation and crop coordinates are those of
+        f32 arithmetic too, not only the threshold decisions.  Costs the batch path its round-4 gain (64 x 1080p: 4.9 -> 6.5 ms).
+        Default off: threshold decisions exact, kept values within ~5e-6 (DESIGN.md 4.3a says what that can and cannot change)."""
+        self.pnet_band = self.split_ro = not on
+        return self
 
     @property
     def _dl(self):
@@ -316,16 +332,24 @@ class MTCNNHIP:
         # the pyramid level is resized inside P-Net conv1's tile load (no f32 level image in HBM)
         h, w = self.p1.out_hw(hs, ws)
         self._tls.level_done = False
+        path = getattr(self._tls, "path", None)                    # what this call ran, for tests / diagnostics (detect_batch resets it)
         if self.fused_pnet and N * h * w * 64 < 2 ** 31:          # the split map is addressed with 32-bit buffer offsets
             t0 = self.thresholds[0]
             lt = math.log(t0 / (1.0 - t0))
-            band = self.pnet_band and N >= 8 and trace is None
+            band = self.pnet_band and N * H * W >= self.batch_min_pixels and trace is None
+            if path is not None:
+                path["fused_levels"] += 1
+                path["band_levels"] += int(band)
             xs = self._new((N, h, w, 64), torch.uint8)     # split-f16 copy of conv1's map
             if band and self.split_pconv1 and cand is not None and h * w >= self.split_pconv1_min_px:
                 # conv1 on the f16 matrix cores -> fused conv2/3/heads -> the conv1 tiles under the band cells' windows, EXACTLY -> the
                 # exact pass + the candidates (csrc/pnet_conv1.hip F16 / LIST, fr_pnet_band_tiles, fr_pnet_finish_levels)
                 p1 = self.p1
-                x = self._f32(N, h, w, 12)                  # the f32 map: written only where an exact window is needed
+                # the f32 map: SPARSE - written only in the 16 x 64-pixel tiles fr_pnet_band_tiles lists (where an exact 5x5 window
+                # is needed), uninitialised elsewhere; read by the exact pass (fr_pnet_finish_levels) inside those windows only
+                x = self._f32(N, h, w, 12)
+                if path is not None:
+                    path["pconv1_mfma_levels"].append((h, w))
                 self.lib.fr_pnet_conv1_band(0, self._fptr(frames), N, H, W, hs, ws, _lib.ptr(p1.w), _lib.ptr(p1.b), _lib.ptr(p1.slope),
                                             None, _lib.ptr(xs), None, None, 0, self._s)
                 head = self._f32(N, h - 4, w - 4, 6)
@@ -351,15 +375,20 @@ class MTCNNHIP:
             x, h, w = self._dconv(None, self.p1, N, hs, ws, frames=frames, y_split=xs)
             head = self._f32(N, h - 4, w - 4, 6)
             ws = self._new((self.lib.fr_pnet23_workspace_bytes(N, h, w) // 4,), torch.float32)
-            defer = getattr(self._tls, "defer", None)     # detect_batch: the exact pass of every level in one launch, behind the pyramid
             self.lib.fr_pnet23_split_f16(_lib.ptr(x), _lib.ptr(xs), N, h, w, *[_lib.ptr(t) for t in self._p23], _lib.ptr(head),
-                                         (1 if (self.p23_all_heads or trace is not None) else 0) | (2 if defer is not None else 0),
+                                         1 if (self.p23_all_heads or trace is not None) else 0,
                                          lt - self.refine_margin, lt + self.refine_margin if band else float("-inf"),
                                          _lib.ptr(self.refined_cells), _lib.ptr(ws), ws.numel() * 4, self._s)
             self._dl = (ws, math.log(t0 / (1.0 - t0)) - self.refine_margin)     # pre-filter for fr_pnet_candidates
-            if defer is not None:
-                defer.append((x, head, ws, h, w))
             return head, h - 4, w - 4
+        # A level too large for 32-bit offsets into the split map (detect_batch cuts batches so that this does not happen; what is
+        # left is a single frame beyond ~ 8K x 16K): the three P-Net layers as generic f32 launches.  Same results, slower - said aloud.
+        if self.fused_pnet and not getattr(self, "_unfused_logged", False):
+            self._unfused_logged = True
+            logging.getLogger(__name__).warning("MTCNNHIP: a %d x %d pyramid level of %d frame(s) exceeds the fused P-Net's 32-bit map "
+                                                "offsets; it runs layer by layer (f32)", hs, ws, N)
+        if path is not None:
+            path["unfused_levels"] += 1
         self._dl = (None, 0.0)
         x, h, w = self._dconv(None, self.p1, N, hs, ws, frames=frames)
         x, h, w = self._dconv(x, self.p2, N, h, w)
@@ -460,7 +489,7 @@ class MTCNNHIP:
             self.phase_marks.append((name, e))
 
     # ---- cascade
-    def detect_batch(self, frames, trace=None, level_streams=None):
+    def detect_batch(self, frames, trace=None, level_streams=None, _out=None, _chunk=False):
         """frames: uint8 [N,H,W,3] BGR device tensor (contiguous).
 
         level_streams: side HIP streams (1 or 2) the pyramid levels 1.. are dealt over; level 0 stays on the caller's
@@ -474,15 +503,44 @@ class MTCNNHIP:
         6.30 with the per-level launches, 6.6 - 6.9 with two side streams - hence the defaults.
 
         Returns device tensors: boxes f32 [N,cap_o,4], scores f32 [N,cap_o], kps f32 [N,cap_o,5,2],
-        counts i32 [N] (faces per frame, in descending-score order)."""
+        counts i32 [N] (faces per frame, in descending-score order).
+
+        ``_tls.path`` (this thread's last call): which arithmetic ran - {"frames", "batch", "chunks", "fused_levels", "band_levels",
+        "pconv1_mfma_levels" [(h, w) of the conv1 maps computed on the f16 matrix cores], "unfused_levels", "split_ro"} - so that a
+        test can assert the path it means to test was the one taken."""
         assert frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[3] == 3 and frames.is_contiguous()
         N, H, W, _ = frames.shape
         lib, t0, t1, t2 = self.lib, *self.thresholds
+        batch = N * H * W >= self.batch_min_pixels
+        few = N <= self.solo_max_frames and not batch
+        if not _chunk:
+            self._tls.path = {"frames": N, "batch": batch, "chunks": 1, "fused_levels": 0, "band_levels": 0, "pconv1_mfma_levels": [],
+                              "unfused_levels": 0, "split_ro": False}
+        # The fused P-Net addresses a level's split conv1 map [N, h, w, 64 B] with 32-bit offsets.  A batch whose largest level
+        # exceeds them (64 x 4K frames: 3.05e9 B) is cut into the fewest equal groups of frames that fit - frames are independent, every
+        # group's final NMS writes its rows of the result tensors - rather than dropping that level to the layer-by-layer f32 path.
+        if self.fused_pnet and trace is None and not _chunk and N > 1:
+            sc0 = pyramid_scales(H, W, self.minsize, self.factor)
+            if sc0:
+                h0, w0 = self.p1.out_hw(int(math.ceil(H * sc0[0])), int(math.ceil(W * sc0[0])))
+                fit = (2 ** 31 - 1) // max(h0 * w0 * 64, 1)
+                if 1 <= fit < N:
+                    ng = -(-N // fit)
+                    per = -(-N // ng)
+                    with torch.cuda.device(self.device):
+                        out = (torch.empty((N, self.cap_o, 4), dtype=torch.float32, device=self.device),
+                               torch.empty((N, self.cap_o), dtype=torch.float32, device=self.device),
+                               torch.empty((N, self.cap_o, 14), dtype=torch.float32, device=self.device),
+                               torch.empty((N,), dtype=torch.int32, device=self.device))
+                    self._tls.path["chunks"] = ng
+                    for n0 in range(0, N, per):
+                        n1 = min(N, n0 + per)
+                        self.detect_batch(frames[n0:n1], None, level_streams, _out=tuple(t[n0:n1] for t in out), _chunk=True)
+                    return out[0], out[1], out[2][..., 4:14].unflatten(-1, (5, 2)), out[3]
         with torch.cuda.device(self.device):
             self._s = _lib.stream_ptr()
             self._tls.cache = None              # (a call that raised may have left these set)
             self._tls.cache_grew = False
-            self._tls.defer = None
             self.lib.stop_recording()
             self._mark("start")
             scales = pyramid_scales(H, W, self.minsize, self.factor)
@@ -502,7 +560,7 @@ class MTCNNHIP:
             if sides is None:                                 # pipelines (bench --pipes) do not couple through them
                 sides = self._sides[main.cuda_stream] = [torch.cuda.Stream(device=self.device) for _ in range(2)]
             nside = max(1, min(2, level_streams if level_streams is not None else self.level_streams))
-            if N < 8 and level_streams is None and self.single_frame_level_streams > 0 and torch.cuda.is_current_stream_capturing():
+            if few and level_streams is None and self.single_frame_level_streams > 0 and torch.cuda.is_current_stream_capturing():
                 # A single frame is a chain of launch latencies.  While a HIP graph is being captured, every level goes to a
                 # stream of its own: the graph then holds the levels' five-kernel chains side by side (640x480 get() + match
                 # under replay 2.21 -> 2.01 ms).  Not in eager calls: the host issues the launches one by one anyway and the
@@ -513,9 +571,9 @@ class MTCNNHIP:
             sides = sides[:nside]
             # An EAGER single-frame call is bound by the interpreter (host issue 0.73 ms against 0.85 ms until the GPU is done,
             # tools/host_time_c1.py): side streams would only add their fork / join events and a stream switch per level
-            solo = trace is not None or self.one_stream or (N < 8 and level_streams is None and not torch.cuda.is_current_stream_capturing())
+            solo = trace is not None or self.one_stream or (few and level_streams is None and not torch.cuda.is_current_stream_capturing())
             record = False
-            if solo and trace is None and N < 8 and not torch.cuda.is_current_stream_capturing():
+            if solo and trace is None and few and _out is None and not torch.cuda.is_current_stream_capturing():
                 caches = self._tls.__dict__.setdefault("caches", {})
                 seqs = self._tls.__dict__.setdefault("seqs", {})
                 key = (N, H, W, main.cuda_stream)
@@ -565,14 +623,7 @@ class MTCNNHIP:
             if not solo:
                 for side in sides:
                     side.wait_stream(main)
-            # Batches: the exact pass and the candidate extraction of ALL levels run as three launches behind the pyramid
-            # (fr_pnet_finish_levels) instead of three per level - with the band-only exact pass a level's launches sat on
-            # their latency floor, twelve levels one after the other
-            finish = (N >= 8 and trace is None and self.fused_pnet and self.merged_level_nms and self.finish_levels and nlev <= 16
-                      and all(N * self.p1.out_hw(int(math.ceil(H * sc)), int(math.ceil(W * sc)))[0]
-                              * self.p1.out_hw(int(math.ceil(H * sc)), int(math.ceil(W * sc)))[1] * 64 < 2 ** 31 for sc in scales))
-            self._tls.defer = [] if finish else None
-            bcs, keep = [], []
+            keep = []
             for li, s in enumerate(scales):
                 side = sides[(li - 1) % len(sides)] if li else sides[0]
                 with (contextlib.nullcontext() if solo else torch.cuda.stream(main if li == 0 else side)):
@@ -580,7 +631,7 @@ class MTCNNHIP:
                         self._s = _lib.stream_ptr()
                     elif record:
                         self._s = ctypes.c_void_p((main if li == 0 else rec_sides[(li - 1) % len(rec_sides)]).cuda_stream)
-                    head, hc, wc = self.pnet_level(frames, s, trace, cand=None if (finish or trace is not None or N < 8) else
+                    head, hc, wc = self.pnet_level(frames, s, trace, cand=None if (trace is not None or not batch) else
                                                    (float(s), t0, cs, lb[li], ls[li], lr[li], lc[li]))
                     nblk = -(-hc * wc // 256)
                     bc = self._i32(N * nblk)
@@ -588,15 +639,14 @@ class MTCNNHIP:
                     dl, dl_min = self._dl
                     if self._tls.level_done:                    # the level extracted its candidates itself
                         keep.append(self._tls.keep)
-                    elif finish:
-                        bcs.append(bc)
+                        self._tls.keep = None
                     else:
                         lib.fr_pnet_candidates(_lib.ptr(head), N, hc, wc, float(s), t0, cs, _lib.ptr(lb[li]), _lib.ptr(ls[li]),
                                                _lib.ptr(lr[li]), _lib.ptr(lc[li]), _lib.ptr(bc), _lib.ptr(prob), _lib.ptr(dl),
                                                dl_min, self._s)
                     # per-level NMS 0.5 -> keep_scale survivors: one launch for all levels behind the loop (default), or
                     # right behind the level's own kernels on the level's stream (merged_level_nms False, batches only)
-                    if N >= 8 and not self.merged_level_nms:
+                    if not few and not self.merged_level_nms:
                         self._nms(lb[li], ls[li], lr[li], 4, lc[li], N, 1, cs, 0, 0.5, 0, ksz, out=(kb[li], ks[li], ka[li], kc[li]))
                     if trace is not None:
                         trace.setdefault("pnet_head", []).append(head)
@@ -615,18 +665,9 @@ class MTCNNHIP:
             for grp in keep:                                    # allocated on a level stream, must outlive the kernels queued there
                 for t in grp:
                     t.record_stream(main)
-            if finish:
-                lv = (_lib.PnetLevel * nlev)()
-                for li, ((x1, head, ws, h1, w1), bc, sc) in enumerate(zip(self._tls.defer, bcs, scales)):
-                    for t in (x1, head, ws, bc):
-                        t.record_stream(main)               # allocated on a level stream, read here
-                    lv[li] = _lib.PnetLevel(x1.data_ptr(), head.data_ptr(), ws.data_ptr(), h1, w1, float(sc), lb[li].data_ptr(),
-                                            ls[li].data_ptr(), lr[li].data_ptr(), lc[li].data_ptr(), bc.data_ptr())
-                lib.fr_pnet_finish_levels(lv, nlev, N, *[_lib.ptr(t) for t in self._p23], t0, cs, self._dl[1],
-                                          _lib.ptr(self.refined_cells), self._s)
-                self._tls.defer = None
+            keep = None                                         # (hundreds of MB at level 0 of 64 x 1080p: back to the allocator now)
             self._mark("pnet")
-            if N < 8 or self.merged_level_nms:
+            if few or self.merged_level_nms:
                 self._nms(lb, ls, lr, 4, lc, nlev * N, 1, cs, 0, 0.5, 0, ksz, out=(kb, ks, ka, kc))
             # cross-level NMS 0.7 -> cap_p
             b1, s1, a1, c1 = self._nms(kb, ks, ka, 4, kc, N, nlev, self.keep_scale, 1, 0.7, 0, self.cap_p)
@@ -637,7 +678,8 @@ class MTCNNHIP:
             # ---- stage 2
             B2 = N * self.cap_p
             crops = None
-            split = self.split_ro and self.fused_crop and trace is None and N >= 8
+            split = self.split_ro and self.fused_crop and trace is None and batch
+            self._tls.path["split_ro"] = bool(split)
             if split:                                   # conv2 on the f16 matrix cores (split precision) + exact pass at the threshold
                 y2, lc2 = self.crop_conv12_split(0, frames, b1, c1, self.cap_p)
                 head2 = self.rnet(None, B2, c1, self.cap_p, x2=y2)
@@ -678,15 +720,17 @@ class MTCNNHIP:
                                 _lib.ptr(ts), _lib.ptr(ta), 14, _lib.ptr(tc), _lib.ptr(prob3), self._s)
             lib.fr_box_refine(_lib.ptr(tb), _lib.ptr(ta), 14, _lib.ptr(tc), N, self.cap_r, 2, self._s)
             self._tls.cache = None                      # what is returned to the caller is never a cached work tensor
-            b3, s3, a3, c3 = self._nms(tb, ts, ta, 14, tc, N, 1, self.cap_r, 0, 0.7, 1, self.cap_o, results=True)
+            b3, s3, a3, c3 = self._nms(tb, ts, ta, 14, tc, N, 1, self.cap_r, 0, 0.7, 1, self.cap_o, out=_out, results=True)
             self._mark("stage3")
             if trace is not None:
                 trace.update(onet_head=head3, onet_prob=prob3)
             if record:
                 calls = lib.stop_recording()         # None: a launch the list cannot express happened (Lib.recording_invalid)
                 if calls and not self._tls.cache_grew:
-                    seqs[key] = self._make_sequence(calls, frames, (b3, s3, a3, c3), cfg)
-                    seqs[key]["events"] = rec_events                 # the call list holds their handles
+                    seq = self._make_sequence(calls, frames, (b3, s3, a3, c3), cfg)
+                    if seq is not None:
+                        seq["events"] = rec_events                   # the call list holds their handles
+                        seqs[key] = seq
             if self._tls.cache_grew and getattr(self._tls, "seqs", None):
                 # a work tensor was replaced in this call (recording or not): a list recorded earlier for this frame shape
                 # holds the freed tensor's pointer
@@ -700,7 +744,9 @@ class MTCNNHIP:
         the frame and the four result tensors - are those the call sites passed WITH that role (_lib.RolePtr: ``_fptr``,
         ``_nms(results=True)``), noted by the recorder beside the call; no slot is found by comparing pointer values.  The
         values only serve as a check: a slot that holds the frame's or a result's address without the role would be a
-        call site that forgot it, and the list is refused."""
+        call site that forgot it, and the list is refused: None is returned, nothing is cached for the frame shape, the call
+        that was being recorded has already produced its (valid, eager) results and later calls stay eager."""
+        log = logging.getLogger(__name__)
         arr = (_lib.Call * len(calls))()
         want = {"frame": frames.data_ptr(), **{"out%d" % i: t.data_ptr() for i, t in enumerate(outs)}}
         fpos, opos = [], [[] for _ in outs]
@@ -710,12 +756,18 @@ class MTCNNHIP:
                 arr[k].a[i] = v
             tagged = dict(roles)
             for i, role in roles:
-                assert slots[i] == want[role], f"call {k}: slot {i} was recorded as '{role}' but holds another tensor"
+                if slots[i] != want[role]:
+                    log.warning("MTCNNHIP: recorded call %d: slot %d carries the role '%s' but holds another tensor; call list refused", k, i, role)
+                    return None
                 (fpos if role == "frame" else opos[int(role[3:])]).append((k, i))
             if fid < 8:                              # (event / stream handles of the pseudo calls are not tensors)
                 for i, v in enumerate(slots):
-                    assert i in tagged or v not in want.values(), f"call {k}: slot {i} holds a patched tensor without its role"
-        assert fpos and all(opos), "the recorded detector call list must mention the frame and every result tensor"
+                    if i not in tagged and v in want.values():
+                        log.warning("MTCNNHIP: recorded call %d: slot %d holds a patched tensor without its role; call list refused", k, i)
+                        return None
+        if not fpos or not all(opos):
+            log.warning("MTCNNHIP: the recorded call list does not mention the frame and every result tensor; refused")
+            return None
         return {"arr": arr, "n": len(calls), "fpos": fpos, "opos": opos, "cfg": cfg,
                 "meta": [(tuple(t.shape), t.dtype) for t in outs]}
 

@@ -135,3 +135,23 @@ def test_reduce_candidates_tie_rule():
     bi, bs = reduce_candidates(s, i)
     assert bi.tolist() == [12, 7, -1]
     assert torch.equal(bs, torch.tensor([0.5, 0.9, -1.0]))
+
+
+def test_bench_refuses_ranks_that_share_a_device():
+    """bench.py gathers {rank, device_index, pci_bus_id, uuid} of every rank after the timed region and exits (code 5) when two
+    ranks report the same device: the first real multi-GPU record must prove that its N ranks sat on N GPUs.
+    The rule itself, on gathered records as an 8-GPU node and a mis-launched job would produce them."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    good = [{"rank": r, "device_index": r, "pci_bus_id": f"0000:{5 + 16 * r:02x}:00", "uuid": f"GPU-{r:04d}"} for r in range(8)]
+    assert bench.ranks_sharing_a_device(good) == []
+    bad = [dict(d) for d in good]
+    bad[5]["pci_bus_id"] = bad[2]["pci_bus_id"]            # LOCAL_RANK ignored: rank 5 landed on rank 2's GPU
+    assert bench.ranks_sharing_a_device(bad) == [(2, 5)]
+    no_pci = [{"rank": r, "device_index": 0, "uuid": "GPU-same"} for r in range(2)]
+    assert bench.ranks_sharing_a_device(no_pci) == [(0, 1)]
+    bare = [{"rank": 0, "device_index": 0}, {"rank": 1, "device_index": 1}, {"rank": 2, "device_index": 1}]
+    assert bench.ranks_sharing_a_device(bare) == [(1, 2)]

@@ -570,8 +570,8 @@ def test_split_ro_cascade_vs_f32_cascade_and_exact_pass():
     from facerecognition_infrenceengine_amd import weights
     from facerecognition_infrenceengine_amd.mtcnn import MTCNNHIP
     st = weights.synth_mtcnn_states()
-    split = MTCNNHIP(*st, device="cuda:0")
-    ref = MTCNNHIP(*st, device="cuda:0")
+    split = MTCNNHIP(*st, device="cuda:0", batch_min_pixels=0)       # (8 small frames: below the default pixel gate of the batch path)
+    ref = MTCNNHIP(*st, device="cuda:0", batch_min_pixels=0)
     ref.split_ro = False
     frs = np.ascontiguousarray(np.stack([synth_frame(360, 640, 40 + i) for i in range(8)]))
     frs[5] = 0                                                        # a frame with no candidate
@@ -612,10 +612,10 @@ def test_pnet_band_mode_vs_exact_kept_cells():
     from facerecognition_infrenceengine_amd import weights
     from facerecognition_infrenceengine_amd.mtcnn import MTCNNHIP, pyramid_scales
     st = weights.synth_mtcnn_states(seed=4321)
-    band = MTCNNHIP(*st, device="cuda:0")
-    plain = MTCNNHIP(*st, device="cuda:0", fused_pnet=False)
-    exact = MTCNNHIP(*st, device="cuda:0")
-    exact.pnet_band = False
+    band = MTCNNHIP(*st, device="cuda:0", batch_min_pixels=0)
+    plain = MTCNNHIP(*st, device="cuda:0", fused_pnet=False, batch_min_pixels=0)
+    exact = MTCNNHIP(*st, device="cuda:0", batch_min_pixels=0).set_exact(True)
+    assert exact.pnet_band is False and exact.split_ro is False
     band.split_ro = exact.split_ro = plain.split_ro = False           # this test isolates the P-Net
     band.refined_cells = torch.zeros(1, dtype=torch.int32, device="cuda")
     exact.refined_cells = torch.zeros(1, dtype=torch.int32, device="cuda")
@@ -660,35 +660,67 @@ def test_pnet_band_mode_vs_exact_kept_cells():
 
 
 def test_all_levels_in_three_launches_equal_per_level_launches():
-    """Batches CAN run the P-Net's exact pass and candidate extraction for ALL pyramid levels in three launches
-    (fr_pnet_finish_levels, MTCNNHIP.finish_levels; off by default: measured slower) instead of three per level: the same cells, the same ordered compaction -
-    the cascade's results are bit-identical to the per-level launches, with the band-only exact pass and with every kept cell
-    re-evaluated, also for a batch whose frames hold no candidate at some levels."""
-    import sys, os
+    """fr_pnet_finish_levels runs the P-Net's exact pass and the ordered candidate extraction for up to 16 pyramid levels per call
+    (the product passes ONE level per call, from MTCNNHIP.pnet_level: the all-levels form was measured slower inside the pipeline
+    and its host switch is gone).  The C entry keeps the general form; checked here through the C ABI: all levels of a 9-frame batch
+    in one call against the per-level launches (fr_pnet23_split_f16's own exact pass + fr_pnet_candidates) - the same counts, the
+    same cells in the same order, the same bits - with the band-only exact pass and with every kept cell re-evaluated, and with a
+    frame that holds no candidate at all."""
+    import math, sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
     from make_golden import synth_frame
-    from facerecognition_infrenceengine_amd import weights
-    from facerecognition_infrenceengine_amd.mtcnn import MTCNNHIP
-    st = weights.synth_mtcnn_states(seed=4321)
-    one = MTCNNHIP(*st, device="cuda:0")
-    per = MTCNNHIP(*st, device="cuda:0")
-    one.finish_levels, per.finish_levels = True, False
-    one.refined_cells = torch.zeros(1, dtype=torch.int32, device="cuda")
-    per.refined_cells = torch.zeros(1, dtype=torch.int32, device="cuda")
+    from facerecognition_infrenceengine_amd import _lib, weights
+    from facerecognition_infrenceengine_amd.mtcnn import MTCNNHIP, pyramid_scales
+    d = MTCNNHIP(*weights.synth_mtcnn_states(seed=4321), device="cuda:0")
+    lib = d.lib
     frs = np.ascontiguousarray(np.stack([synth_frame(300, 500, 80 + k) for k in range(9)]))
     frs[4] = 0
-    x = torch.from_numpy(frs).cuda()
+    fr = torch.from_numpy(frs).cuda()
+    N, H, W = 9, 300, 500
+    t0, cs = d.thresholds[0], d.cap_scale
+    lt = math.log(t0 / (1.0 - t0))
+    s0 = torch.cuda.current_stream().cuda_stream
+    scales = pyramid_scales(H, W)
+    p23 = [_lib.ptr(t) for t in d._p23]
     for band in (True, False):
-        one.pnet_band = per.pnet_band = band
-        one.refined_cells.zero_(); per.refined_cells.zero_()
-        a, b = one.detect_batch(x), per.detect_batch(x)
-        torch.cuda.synchronize()
-        assert torch.equal(a[3], b[3]) and int(a[3].sum()) >= 8 and int(a[3][4]) == 0
-        assert int(one.refined_cells[0]) == int(per.refined_cells[0]) > 0
-        for f in range(9):
-            n = int(a[3][f])
-            for u, v in zip(a[:3], b[:3]):
-                assert torch.equal(u[f, :n], v[f, :n])
+        hi = lt + d.refine_margin if band else float("-inf")
+        lists, keep = {}, []
+        for mode in ("per_level", "one_call"):
+            nref = torch.zeros(1, dtype=torch.int32, device="cuda")
+            lb, ls, lr, lc = (torch.zeros(len(scales), N, cs, 4, device="cuda"), torch.zeros(len(scales), N, cs, device="cuda"),
+                              torch.zeros(len(scales), N, cs, 4, device="cuda"), torch.zeros(len(scales), N, dtype=torch.int32, device="cuda"))
+            lv = (_lib.PnetLevel * len(scales))()
+            with torch.cuda.device("cuda:0"):
+                d._s = s0
+                for li, sc in enumerate(scales):
+                    hs, ws = int(math.ceil(H * sc)), int(math.ceil(W * sc))
+                    h, w = d.p1.out_hw(hs, ws)
+                    xs = torch.empty((N, h, w, 64), dtype=torch.uint8, device="cuda")
+                    x, _, _ = d._dconv(None, d.p1, N, hs, ws, frames=fr, y_split=xs)
+                    head = torch.empty((N, h - 4, w - 4, 6), device="cuda")
+                    wsp = torch.empty(lib.fr_pnet23_workspace_bytes(N, h, w) // 4, device="cuda")
+                    bc = torch.zeros(N * (-(-(h - 4) * (w - 4) // 256)), dtype=torch.int32, device="cuda")
+                    lib.fr_pnet23_split_f16(_lib.ptr(x), _lib.ptr(xs), N, h, w, *p23, _lib.ptr(head), 0 if mode == "per_level" else 2,
+                                            lt - d.refine_margin, hi, _lib.ptr(nref), _lib.ptr(wsp), wsp.numel() * 4, s0)
+                    if mode == "per_level":
+                        lib.fr_pnet_candidates(_lib.ptr(head), N, h - 4, w - 4, float(sc), t0, cs, _lib.ptr(lb[li]), _lib.ptr(ls[li]),
+                                               _lib.ptr(lr[li]), _lib.ptr(lc[li]), _lib.ptr(bc), None, _lib.ptr(wsp), lt - d.refine_margin, s0)
+                    else:
+                        lv[li] = _lib.PnetLevel(x.data_ptr(), head.data_ptr(), wsp.data_ptr(), h, w, float(sc), lb[li].data_ptr(),
+                                                ls[li].data_ptr(), lr[li].data_ptr(), lc[li].data_ptr(), bc.data_ptr())
+                    keep.append((x, xs, head, wsp, bc))
+                if mode == "one_call":
+                    lib.fr_pnet_finish_levels(lv, len(scales), N, *p23, t0, cs, lt - d.refine_margin, _lib.ptr(nref), s0)
+            torch.cuda.synchronize()
+            lists[mode] = (lb, ls, lr, lc, int(nref[0]))
+        (ab, as_, ar, ac, na), (bb, bs, br, bc_, nb) = lists["per_level"], lists["one_call"]
+        assert torch.equal(ac, bc_) and int(ac.sum()) >= 100 and int(ac[:, 4].sum()) == 0
+        assert na == nb > 0
+        for li in range(len(scales)):
+            for f in range(N):
+                n = min(int(ac[li, f]), cs)
+                assert torch.equal(ab[li, f, :n], bb[li, f, :n]) and torch.equal(as_[li, f, :n], bs[li, f, :n])
+                assert torch.equal(ar[li, f, :n], br[li, f, :n])
 
 
 def test_split_gemm_tail_layers_vs_f32_layers():
@@ -730,8 +762,8 @@ def test_pnet_conv1_on_matrix_cores_with_exact_tiles_under_the_band():
     from facerecognition_infrenceengine_amd import weights, _lib
     from facerecognition_infrenceengine_amd.mtcnn import MTCNNHIP, pyramid_scales
     st = weights.synth_mtcnn_states(seed=4321)
-    mc = MTCNNHIP(*st, device="cuda:0")
-    ref = MTCNNHIP(*st, device="cuda:0")
+    mc = MTCNNHIP(*st, device="cuda:0", batch_min_pixels=0)
+    ref = MTCNNHIP(*st, device="cuda:0", batch_min_pixels=0)
     assert mc.split_pconv1 and mc.pnet_band
     mc.split_pconv1_min_px = 25                                         # every level (the default takes the large ones only)
     ref.split_pconv1 = False

@@ -480,7 +480,8 @@ def test_c2_geometry_1080p_frame_vs_oracle(app):
 
 
 def test_eight_frame_batch_slot_path_vs_oracle(app):
-    """An 8-frame batch through the sync-free slot path (what bench.py times), every frame against the oracle."""
+    """Eight small frames through the sync-free slot path, every frame against the oracle (16.6 Mpixel and below run the all-f32
+    detector on level streams; the batch arithmetic is under the oracle in the *_batch_path_* tests at the end of this file)."""
     from make_golden import synth_frame
     frs = np.ascontiguousarray(np.stack([synth_frame(360, 640, 40 + i) for i in range(8)]))
     r = app.detect_embed_slots(torch.from_numpy(frs).cuda())
@@ -593,12 +594,14 @@ def test_camera_batcher_equals_per_frame_recognition(app):
     assert proc.recognize_batch(frames[:2], "nobody") is None          # unknown company: no gallery, frames untouched
 
 
-def _oracle_frame(frame, cap_o=16):
+def _oracle_frame(frame, cap_o=16, embed=True):
     """oracle_pipeline with the engine's face-slot count (the oracle's ``cap_o`` is the detector's last capacity)"""
     from facerecognition_infrenceengine_amd import weights
     p, r, o = weights.synth_mtcnn_states()
     st = weights.synth_iresnet_state("r100")
     b, s, k = odetect.detect(frame, p, r, o, cap_o=cap_o)
+    if not embed:
+        return b, s, k, None
     crops = [oalign.norm_crop(frame, kk)[0] for kk in k]
     x = torch.from_numpy(np.stack([oalign.crop_to_net(c) for c in crops]))
     return b, s, k, onets.iresnet_forward(st, x, weights.IRESNET_LAYERS["r100"]).numpy()
@@ -710,3 +713,172 @@ def test_c3_4k_frame_sixteen_slots_through_get_vs_oracle():
         c2 = (e2[f] * oemb).sum(1) / (np.linalg.norm(e2[f], axis=1) * np.linalg.norm(oemb, axis=1))
         assert (1 - c2).max() < 1e-3
         np.testing.assert_allclose(r["bbox"][f, :n].cpu().numpy(), ob, atol=2e-2)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The path bench.py times, under the suite's oracle (/root/reference/infrenceServer.py:528): batches of
+# >= MTCNNHIP.batch_min_pixels pixels (22 M: 11 full-HD frames, 3 4K frames) take the BATCH detector - band-only exact P-Net pass, P-Net conv1 of the levels with
+# >= split_pconv1_min_px map pixels and every R-/O-Net layer on the f16 matrix cores with split-precision operands, exact f32
+# passes at the thresholds - and these tests ASSERT that path was the one taken (MTCNNHIP._tls.path) besides comparing every
+# frame with the CPU oracle, so that a change of the gates cannot silently turn them into tests of the all-f32 detector.
+def _oracle_threads(n=16):
+    """The CPU oracle's convs are fastest on ~16 torch threads whatever the host has (bench.py cpu_baseline_sweep)."""
+    old = torch.get_num_threads()
+    torch.set_num_threads(min(n, os.cpu_count() or n))
+    return old
+
+
+def _assert_batch_path(det, nframes, nlevels, mfma_levels_min):
+    p = det._tls.path
+    assert p["frames"] == nframes and p["batch"] and p["unfused_levels"] == 0, p
+    assert p["fused_levels"] == p["band_levels"] == nlevels * p["chunks"], p
+    assert len(p["pconv1_mfma_levels"]) >= mfma_levels_min * p["chunks"], p
+    assert all(h * w >= det.split_pconv1_min_px for h, w in p["pconv1_mfma_levels"]), p
+    assert p["split_ro"], p
+    lists = {net: int(lc[0]) for net, lc in det._ro_lists.items()}          # crops the exact f32 R-/O-Net pass took (last chunk)
+    assert set(lists) == {0, 1} and all(0 <= lists[n] <= det.ro_list_cap[n] for n in lists), (lists, det.ro_list_cap)
+    return p, lists
+
+
+def _check_slots_vs_oracle(r, frs, which, cap_o, px_tol, cos_tol=1e-3, embed=None):
+    """frames ``which`` of the slot-path result ``r`` against the CPU oracle (``embed``: the frames whose faces also go through
+    the oracle's fp32 r100 - default all of ``which``); returns [(slot, oracle embedding)] of those"""
+    counts = r["counts"].cpu().numpy()
+    cap = r["bbox"].shape[1]
+    emb = r["embedding"].cpu().numpy().reshape(len(counts), cap, 512)
+    out, worst = [], 0.0
+    old = _oracle_threads()
+    try:
+        for i in which:
+            with_emb = embed is None or i in embed
+            ob, os_, ok, oemb = _oracle_frame(frs[i], cap_o=cap_o, embed=with_emb)
+            n = len(os_)
+            assert counts[i] == n >= 1, (i, counts[i], n)
+            np.testing.assert_allclose(r["bbox"][i, :n].cpu().numpy(), ob, atol=px_tol)
+            np.testing.assert_allclose(r["det_score"][i, :n].cpu().numpy(), os_, atol=5e-5)
+            np.testing.assert_allclose(r["kps"][i, :n].cpu().numpy(), ok, atol=px_tol)
+            if not with_emb:
+                continue
+            e = emb[i, :n]
+            cos = (e * oemb).sum(1) / (np.linalg.norm(e, axis=1) * np.linalg.norm(oemb, axis=1))
+            worst = max(worst, float((1 - cos).max()))
+            assert (1 - cos).max() < cos_tol, (i, cos)
+            out += [(i * cap + j, oemb[j]) for j in range(n)]
+    finally:
+        torch.set_num_threads(old)
+    return out, worst
+
+
+def _planted_ids_equal(r, faces, rows, seed, scan="f32"):
+    """top-1 ids of the GPU's embeddings == the oracle's own, against a gallery with one planted row per face"""
+    from facerecognition_infrenceengine_amd.gallery import GalleryMatcher
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((rows, 512)).astype(np.float32)
+    planted = rng.choice(rows, len(faces), replace=False)
+    oemb = np.stack([e for _, e in faces])
+    G[planted] = oemb / np.linalg.norm(oemb, axis=1, keepdims=True) + 0.02 * rng.standard_normal(oemb.shape).astype(np.float32)
+    G /= np.linalg.norm(G, axis=1, keepdims=True)
+    m = GalleryMatcher("cuda:0", scan=scan)
+    m.set_rows(list(range(rows)), G, normalise=False)
+    Q = r["normed_embedding"][torch.tensor([s for s, _ in faces], device="cuda")].contiguous()
+    idx, score = m.match_device(Q)
+    oi, _ = omatch.match_rows_fast(np.stack([omatch.renormalise(e / np.linalg.norm(e)) for e in oemb]), G)
+    assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(oi, planted)
+    dec = m.decide_device(idx, score, 0.4).cpu().numpy()
+    assert (dec == 1).all()
+
+
+def test_c2_batch_path_twelve_1080p_frames_vs_oracle_and_path_taken(app):
+    """BASELINE config C2's step at a fifth of its batch: 12 x 1080p frames (24.9 Mpixel: the smallest full-HD batch on the batch
+    path) through detect_embed_slots with every default left alone; EVERY frame's detections against the CPU oracle (counts,
+    boxes / landmarks, scores) and the faces of six frames through its fp32 r100 as well (embeddings, top-1 ids on planted rows);
+    the path asserted: all 12 levels through the band-only exact pass, level 0 (pooled conv1 map 323 x 575) through P-Net conv1
+    on the f16 matrix cores with exact tiles under the band, the R-/O-Net split cascade with its exact lists inside their
+    capacities, and a non-zero number of exactly re-evaluated P-Net cells."""
+    from make_golden import synth_frame
+    frs = np.ascontiguousarray(np.stack([synth_frame(1080, 1920, 200 + i) for i in range(12)]))
+    det = app.det
+    assert 8 * 1080 * 1920 < det.batch_min_pixels <= 12 * 1080 * 1920
+    det.refined_cells = torch.zeros(1, dtype=torch.int32, device="cuda")
+    try:
+        r = app.detect_embed_slots(torch.from_numpy(frs).cuda())
+        torch.cuda.synchronize()
+        refined = int(det.refined_cells[0])
+    finally:
+        det.refined_cells = None
+    p, lists = _assert_batch_path(det, 12, 12, 1)
+    assert max(p["pconv1_mfma_levels"]) == (323, 575), p
+    assert refined > 0
+    faces, worst = _check_slots_vs_oracle(r, frs, range(12), det.cap_o, 1e-2, embed=(0, 2, 5, 7, 8, 11))
+    print(f"\nC2 batch path, 12 x 1080p: {len(faces)} faces vs oracle, max 1-cos {worst:.2e}; exact P-Net cells {refined}, "
+          f"exact R-/O-Net crops {lists}, path {p}")
+    assert len(faces) >= 24
+    _planted_ids_equal(r, faces, 10_000, 21)
+
+
+def test_c3_batch_path_eight_4k_frames_vs_oracle_and_path_taken():
+    """BASELINE config C3's batch form: 8 x 4K frames, sixteen face slots per frame, through detect_embed_slots (the 128-face
+    embed forward = the stage-14 kernel's smallest batch); frames are independent, so two of the eight go through the CPU
+    oracle (a 4K frame costs it ~20 GFLOP of P-Net alone).  Path asserted as for C2 (14 levels; cap_scale overflows at the
+    large levels, where the oracle keeps the first 2048 cells in raster order as the kernels do)."""
+    from facerecognition_infrenceengine_amd import FaceAnalysis
+    from make_golden import synth_frame
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a16 = FaceAnalysis(name="synthetic", arch="r100", cap_o=16).prepare(ctx_id=0)
+    frs = np.ascontiguousarray(np.stack([synth_frame(2160, 3840, 300 + i) for i in range(8)]))
+    r = a16.detect_embed_slots(torch.from_numpy(frs).cuda())
+    torch.cuda.synchronize()
+    p, lists = _assert_batch_path(a16.det, 8, 14, 3)
+    assert p["chunks"] == 1
+    assert int(r["counts"].sum()) >= 64
+    faces, worst = _check_slots_vs_oracle(r, frs, (1, 6), 16, 2e-2)
+    print(f"\nC3 batch path, 8 x 4K: {len(faces)} faces of frames 1, 6 vs oracle, max 1-cos {worst:.2e}; exact crops {lists}, path {p}")
+    _planted_ids_equal(r, faces, 10_000, 22)
+
+
+def test_c5_batch_path_twelve_1080p_frames_fp8_vs_oracle_and_path_taken():
+    """BASELINE config C5 on the batch path: calibrate_fp8 (on other frames), then 12 x 1080p frames with four face slots each -
+    the detector on its batch path (asserted), the embed net with 63 fp8 convs, the fp8 coarse scan + exact re-rank; five of the
+    twelve frames against the CPU oracle: detector outputs as on the f16 path, fp8 embeddings within north_star's 1 - cos < 1e-3 of
+    the fp32 oracle, ids equal on planted rows."""
+    from facerecognition_infrenceengine_amd import FaceAnalysis
+    from make_golden import synth_frame
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a8 = FaceAnalysis(name="synthetic", arch="r100", cap_o=4).prepare(ctx_id=0)
+    calib = np.ascontiguousarray(np.stack([synth_frame(1080, 1920, 90 + i) for i in range(4)]))
+    assert a8.calibrate_fp8(calib) == 63 and a8.rec.fp8
+    frs = np.ascontiguousarray(np.stack([synth_frame(1080, 1920, 400 + i) for i in range(12)]))
+    r = a8.detect_embed_slots(torch.from_numpy(frs).cuda())
+    torch.cuda.synchronize()
+    p, lists = _assert_batch_path(a8.det, 12, 12, 1)
+    faces, worst = _check_slots_vs_oracle(r, frs, (0, 3, 5, 7, 10), 4, 1e-2)
+    print(f"\nC5 batch path, 12 x 1080p: {len(faces)} faces vs oracle, fp8 embed max 1-cos {worst:.2e}; exact crops {lists}")
+    assert len(faces) >= 8
+    _planted_ids_equal(r, faces, 20_000, 23, scan="f8")
+
+
+def test_sixty_four_4k_frames_are_cut_into_groups_that_fit_the_fused_pnet():
+    """64 x 4K frames: level 0's split conv1 map (64 x 647 x 1151 x 64 B = 3.05e9 B) exceeds the fused P-Net's 32-bit offsets.
+    detect_batch cuts the batch into two groups of 32 (MTCNNHIP._tls.path["chunks"]) instead of dropping the level to the
+    layer-by-layer f32 path: every frame's faces equal those of the same frame inside an 8-frame batch (the same batch path;
+    frames are independent), and no level ran unfused."""
+    from facerecognition_infrenceengine_amd import weights
+    from facerecognition_infrenceengine_amd.mtcnn import MTCNNHIP
+    from make_golden import synth_frame
+    det = MTCNNHIP(*weights.synth_mtcnn_states(), device="cuda:0", cap_o=4)
+    eight = np.ascontiguousarray(np.stack([synth_frame(2160, 3840, 500 + i) for i in range(8)]))
+    big = torch.from_numpy(eight).cuda().repeat(8, 1, 1, 1).contiguous()           # 64 frames, 1.6 GB
+    want = det.detect_batch(big[:8].contiguous())
+    assert det._tls.path["chunks"] == 1
+    got = det.detect_batch(big)
+    torch.cuda.synchronize()
+    p = det._tls.path
+    assert p["chunks"] == 2 and p["unfused_levels"] == 0 and p["fused_levels"] == 28 and p["split_ro"], p
+    assert int(want[3].sum()) >= 16
+    for f in range(64):
+        n = int(want[3][f % 8])
+        assert int(got[3][f]) == n
+        for a, b in zip(want[:3], got[:3]):
+            assert torch.equal(a[f % 8, :n], b[f, :n]), f

@@ -46,6 +46,10 @@ def test_bench_gpus2_launches_itself_and_prints_rank0_line():
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and "self_check" in d
     # the N > 1 line explains itself: the exchange's four parts, bracketed by HIP events inside ShardedGalleryMatcher.match
     assert set(d["exchange_ms"]) == {"gather_q", "scan", "gather_c", "reduce", "samples"} and d["exchange_ms"]["samples"] >= 3
+    # ... and says who ran where: one entry per rank with the device it used (both on cuda:0 here, and flagged as a rehearsal;
+    # without --same-device two ranks reporting one PCI address make the run exit with code 5: tests/test_distributed.py)
+    assert [r["rank"] for r in d["ranks"]] == [0, 1] and all(r["device_index"] == 0 for r in d["ranks"])
+    assert d["ranks_distinct_devices"] is False and all("pci_bus_id" in r or "uuid" in r for r in d["ranks"])
 
 
 def test_bench_force_exchange_runs_both_all_gathers_over_rccl():
@@ -66,3 +70,4 @@ def test_bench_force_exchange_runs_both_all_gathers_over_rccl():
     assert d["planted_top1"]["faces"] > 0 and d["planted_top1"]["matched_own_row"] > 0      # ids came through the exchange
     ex = d["exchange_ms"]                                                                    # ... and its parts are timed
     assert set(ex) == {"gather_q", "scan", "gather_c", "reduce", "samples"} and all(ex[k] > 0 for k in ("gather_q", "scan", "gather_c", "reduce"))
+    assert len(d["ranks"]) == 1 and d["ranks"][0]["rank"] == 0 and d["ranks_distinct_devices"] is True
