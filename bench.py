@@ -264,9 +264,11 @@ def main():
                          "C3 20 780 / 18 800 / 18 340 / 20 880 - with one pair the one-workgroup-per-CU stage kernels of step i find the "
                          "CUs free of step i + 2's detector blocks")
     ap.add_argument("--embed-group", type=int, default=0,
-                    help="consecutive steps whose face slots share ONE embed forward (FaceAnalysis.detect_embed_slots(crops_out=...) + "
-                         "embed_slots).  Default: 2 for C3 - a step is 8 x 4K frames x 16 slots = 128 faces, half of the 256 CUs for the "
-                         "one-workgroup-per-face stage kernels; two steps' crops side by side fill them - and 1 otherwise")
+                    help="A/B: consecutive steps whose face slots share ONE embed forward (FaceAnalysis.detect_embed_slots(crops_out=...) + "
+                         "embed_slots).  Default 1.  Measured for C3 (a step = 8 x 4K frames x 16 slots = 128 faces = the stage kernels on half "
+                         "of the CUs), same box: 1: 20 620 faces/s (5.37 ms/step), 2: 19 030 (5.82) - the CUs a 128-workgroup stage launch "
+                         "leaves free are where the NEXT step's detector runs meanwhile (detect 2.7 + align/embed 4.3 alone = 7.0 ms against "
+                         "5.4 per pipelined step); a 256-face forward owns every CU and the step becomes the sum (profiles/r05_c3_embed_group.txt)")
     ap.add_argument("--one-stream", action="store_true", help="detector and embedder on one stream (no overlap)")
     ap.add_argument("--det-sides", type=int, default=None, help="A/B: side streams the detector deals pyramid levels 1.. over")
     ap.add_argument("--embed-chunk", type=int, default=None, help="A/B: faces per embed forward (IResNetHIP.max_chunk; default 256)")
@@ -383,7 +385,7 @@ def main():
     if args.pipes <= 0:
         args.pipes = 1 if FRAMES >= 16 else 2
     if args.embed_group <= 0:
-        args.embed_group = 2 if (args.workload == "C3" and two) else 1
+        args.embed_group = 1
     G = args.embed_group
     pipes = []
     for _ in range(args.pipes if two else 1):
@@ -562,6 +564,14 @@ def main():
     exchange_ms = sharded.exchange_ms()
     sharded.timing = None
     stage_ms = {"detect": round(float(st3[0]), 3), "align_embed": round(float(st3[1]), 3), "match": round(float(st3[2]), 3)}
+    # which detector arithmetic the batches took, and how many crops its exact f32 R-/O-Net pass re-evaluated against the capacity of
+    # its work lists (a crop dropped past the capacity would keep a split-precision threshold decision: the run fails on it)
+    det_path = dict(app.det._tls.path)
+    det_path["pconv1_mfma_levels"] = len(det_path["pconv1_mfma_levels"])
+    lists = getattr(app.det, "_ro_lists", None) if det_path.get("split_ro") else None
+    if lists:
+        det_path["exact_crops"] = {"rnet": int(lists[0][0]), "onet": int(lists[1][0]), "list_caps": list(app.det.ro_list_cap)}
+        det_path["exact_list_overflow"] = bool(int(lists[0][0]) > app.det.ro_list_cap[0] or int(lists[1][0]) > app.det.ro_list_cap[1])
 
     # ---- instrumented pass (outside the timed region): HIP events around every conv launch
     app.rec.profile = []
@@ -689,7 +699,7 @@ def main():
                "p50_batch_latency_ms": round(float(np.percentile(batch_ms, 50)), 3),
                "p95_batch_latency_ms": round(float(np.percentile(batch_ms, 95)), 3),
                "p50_face_latency_ms": round(float(np.percentile(batch_ms, 50)) / max(faces / world / args.steps, 1), 4),
-               "stage_ms_alone": stage_ms, **({"exchange_ms": exchange_ms} if exchange_ms is not None else {}),
+               "stage_ms_alone": stage_ms, "detector_path": det_path, **({"exchange_ms": exchange_ms} if exchange_ms is not None else {}),
                **({"ranks": ranks_rec, "ranks_distinct_devices": not args.same_device} if ranks_rec is not None else {}), **side,
                "self_check": f"all {len(results)} timed steps == sequential single-stream re-run (ids, decisions, counts)",
                "planted_top1": {"faces": plant_all, "matched_own_row": plant_hit,
@@ -699,6 +709,8 @@ def main():
                                         "reproduces them through the scan, not that they are right - oracle_check does that"},
                "roofline": roofline}
         fail = None
+        if det_path.get("exact_list_overflow"):
+            fail = "the detector's exact R-/O-Net work list overflowed its capacity (MTCNNHIP.ro_list_cap)"
         if world == 1 and not args.no_cpu_baseline:
             # CPU oracle leg on copies of the first frames of batch 0, against the gallery the GPU scans; its per-frame
             # results are ALSO the check of the GPU's results for those frames (oracle_check; a mismatch fails the run)
@@ -717,7 +729,7 @@ def main():
             out["cpu_baseline_sweep"] = [{"cores": r["cores"], "value": r["value"], "ms_per_pass": r["ms_per_pass"]} for r in sweep]
             out["oracle_check"] = oracle_check(res0, gpu0, 1e-3)
             if not out["oracle_check"]["ok"]:
-                fail = "oracle_check failed: the GPU's results for batch 0 differ from the CPU oracle's"
+                fail = (fail + "; " if fail else "") + "oracle_check failed: the GPU's results for batch 0 differ from the CPU oracle's"
         print(json.dumps(out), flush=True)
         if fail:
             print(fail, file=sys.stderr, flush=True)

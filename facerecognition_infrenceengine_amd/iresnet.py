@@ -49,8 +49,6 @@ STAGE14_MIN_BATCH = 128
 # modes (<= small_batch faces: the prepared single-frame sequence runs fr_conv_nhwc_f16, and a mode's kernels are one set).
 WALK64_SKIP = range(129, 160)
 STAGE28_MIN_BATCH = 144     # fr_conv_stage28_f16: one workgroup per face, as the 14x14 stage kernel
-# faces per group of the net's front (IResNetHIP.front112_chunk / front56_chunk; 0 = whole batch), used from FRONT_MIN_BATCH faces
-FRONT112_CHUNK, FRONT56_CHUNK, FRONT_MIN_BATCH = 0, 0, 160
 
 
 def _bn_fold(st, prefix, n, conv=None):
@@ -255,16 +253,6 @@ class IResNetHIP:
         self.fp8 = False             # enable_fp8(): eligible body convs run on the fp8 matrix cores
         self.use_stage28 = True      # False: the 28x28 stage runs layer by layer whatever the batch (A/B, tests)
         self.use_stage14 = True      # False: the 14x14 stage runs layer by layer whatever the batch (A/B, tests)
-        # The 112x112 / 56x56 front of the net (stem .. the 56 -> 28 entry block) is HBM-bound layer by layer: a 256-face batch's
-        # 112x112x64 map is 411 MB, more than the 256 MB memory-side cache, and it is written and read four times.  Run in groups
-        # of faces whose maps DO fit (front112_chunk faces through stem + block 0, front56_chunk faces through the 56x56 blocks)
-        # the same launches find their inputs on-die.  0: whole batch (see FRONT_* below for the measured defaults).
-        self.front112_chunk, self.front56_chunk = FRONT112_CHUNK, FRONT56_CHUNK
-        self.front_end = 0           # blocks [0, front_end) = the front: up to and including the first block with 128 output channels
-        for i, (c1, c2, sc) in enumerate(self.blocks):
-            if c2.cout == 128 and c2.stride == 2 and c1.cin == 64:
-                self.front_end = i + 1
-                break
         self.stage14_f8 = None       # enable_fp8(): the run's fp8 form (fr_conv_stage14_f8)
         self._calib = None
 
@@ -635,36 +623,6 @@ class IResNetHIP:
             self.lib.fr_conv_nhwc_f16(ctypes.byref(a), _lib.stream_ptr())
         return y, Ho, Wo
 
-    def _run_blocks(self, h, H, W, B, first, last, y_last=None):
-        """blocks [first, last) layer by layer in f16 on B faces (no taps, no fp8, no calibration: the front of the net);
-        the last conv writes into ``y_last`` when given.  Returns (h, H, W)."""
-        for bi_ in range(first, last):
-            c1, c2, sc = self.blocks[bi_]
-            mid, _, _ = self._conv(h, c1, B, H, W)
-            fz = self.fused_sc.get(bi_) if self.fuse_shortcut else None
-            y = y_last if bi_ == last - 1 else None
-            if fz is not None:
-                h, H, W = self._conv(mid, fz, B, H, W, x2=h, y=y)
-            else:
-                short = h if sc is None else self._conv(h, sc, B, H, W)[0]
-                h, H, W = self._conv(mid, c2, B, H, W, residual=short, y=y)
-        return h, H, W
-
-    def _front(self, x, B):
-        """stem .. block front_end - 1 in groups of faces whose maps fit the memory-side cache -> f16 [B,28,28,128]"""
-        S56 = self.front56_chunk or B
-        S112 = min(self.front112_chunk or S56, S56)
-        out = torch.empty((B, 28, 28, 128), dtype=torch.float16, device=self.device)
-        for b0 in range(0, B, S56):
-            nb = min(S56, B - b0)
-            h56 = torch.empty((nb, 56, 56, 64), dtype=torch.float16, device=self.device)
-            for a0 in range(0, nb, S112):
-                na = min(S112, nb - a0)
-                hs, _, _ = self._conv(x[b0 + a0:b0 + a0 + na], self.stem, na, 112, 112)
-                self._run_blocks(hs, 112, 112, na, 0, 1, y_last=h56[a0:a0 + na])
-            self._run_blocks(h56, 56, 56, nb, 1, self.front_end, y_last=out[b0:b0 + nb])
-        return out, 28, 28
-
     def forward(self, x, taps=None):
         assert x.dtype == torch.float16 and x.shape[1:] == (112, 112, 8) and x.is_contiguous()
         B = x.shape[0]
@@ -785,13 +743,7 @@ class IResNetHIP:
                 self.lib.fr_conv_sequence(arr, n, _lib.stream_ptr())
                 self._fc(h, B, emb, normed)
             return
-        front = 0
-        if (B >= FRONT_MIN_BATCH and taps is None and self._calib is None and self.front_end > 1 and self.blocks[1][0].cin == 64
-                and (self.front112_chunk or self.front56_chunk)):
-            h, H, W = self._front(x, B)
-            front = self.front_end
-        else:
-            h, H, W = self._conv(x, self.stem, B, 112, 112)
+        h, H, W = self._conv(x, self.stem, B, 112, 112)
         if taps is not None:
             taps["stem"] = h
         li = 0
@@ -810,8 +762,6 @@ class IResNetHIP:
             if s28_n < 2:
                 s28_n = 0
         for bi_, (c1, c2, sc) in enumerate(self.blocks):
-            if bi_ < front:
-                continue
             if s28_first <= bi_ < s28_first + s28_n:
                 if bi_ == s28_first:
                     h = self._run_stage28(h, B, s28_n)

@@ -363,7 +363,13 @@ int fr_ro_gemm_split(int layer, const float* x, const void* w_packed, const floa
 /* The exact pass's work list: the valid slots whose logit difference head[s][1] - head[s][0] lies within `margin` of
  * logit_thr = ln(t / (1 - t)) (t: the stage's probability threshold) are appended to list (any order); *list_count = how
  * many there are (may exceed list_cap: entries past it are dropped, consumers clamp).  head f32 [nframes*cap][nhead].
- * *list_count must be 0 on entry (fr_ro_conv2_split's zero_word, or the caller's memset). */
+ * *list_count must be 0 on entry (fr_ro_conv2_split's zero_word, or the caller's memset).
+ * OVERFLOW: the slots dropped past list_cap keep their split-precision heads - their threshold decision is then NOT the f32
+ * one.  Nothing signals it on the device; a caller that must know compares *list_count with list_cap after the cascade
+ * (MTCNNHIP._ro_lists; the batch-path tests and bench.py's line do) and raises list_cap or re-runs the stage on the f32 layers.
+ * The f32 layers that follow take the list's own counter as their `counts` with cap = list_cap: fr_dconv_mfma_f32 and
+ * fr_ro_gemm_split only test slot < counts[f], so a counter ABOVE list_cap is tolerated there (every one of the list_cap rows
+ * is computed, none beyond). */
 int fr_ro_margin_list(const float* head, int nhead, const int32_t* counts, int nframes, int cap, float logit_thr,
                       float margin, int32_t* list, int32_t* list_count, int list_cap, fr_stream_t stream);
 /* dst[list[i]][:] = src[i][:] for i < min(*list_count, list_cap): the exactly re-evaluated head rows go back to their slots. */
