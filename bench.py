@@ -41,7 +41,7 @@ GALLERY_ROWS = 10_000
 FACES_PER_FRAME = 4                    # O-Net cap (C2 keeps F = 4 -> 256 faces/batch)
 MFMA_PEAK_TFLOPS = 2500.0              # dense f16/bf16 (MI355X_MICROARCH.md)
 MFMA_PEAK_TFLOPS_F8 = 5000.0           # dense fp8 (block-scaled MFMA with unit scales)
-PMC_FILE = "profiles/r04_pmc_traffic.json"
+PMC_FILE = "profiles/r05_pmc_traffic.json"
 
 
 def synth_frames(n, h, w, seed, device):
@@ -245,8 +245,6 @@ def main():
     ap.add_argument("--ingest", default="resident", choices=["resident", "pinned"],
                     help="resident: frames already in HBM (the headline metric); pinned: every step's frames cross "
                          "PCIe from a pinned host ring on a copy stream (reported in DESIGN.md, never the headline)")
-    ap.add_argument("--ingest-chunks", type=int, default=1, help="A/B (pinned ingest): frame groups a step's upload is cut into")
-    ap.add_argument("--ingest-streams", type=int, default=1, help="A/B (pinned ingest): copy streams the groups are dealt over")
     ap.add_argument("--ingest-ahead", type=int, default=2,
                     help="pinned ingest: a step's upload is issued this many steps before the step itself is enqueued (the capture side hands a "
                          "batch over when its ring slot is full, not when the GPU asks for it).  Measured, same box (tools/ab_ingest.sh): resident "
@@ -271,8 +269,6 @@ def main():
                          "5.4 per pipelined step); a 256-face forward owns every CU and the step becomes the sum (profiles/r05_c3_embed_group.txt)")
     ap.add_argument("--one-stream", action="store_true", help="detector and embedder on one stream (no overlap)")
     ap.add_argument("--det-sides", type=int, default=None, help="A/B: side streams the detector deals pyramid levels 1.. over")
-    ap.add_argument("--embed-chunk", type=int, default=None, help="A/B: faces per embed forward (IResNetHIP.max_chunk; default 256)")
-    ap.add_argument("--det-level-nms", default=None, choices=["merged", "per-level"], help="A/B: per-level NMS as one launch or one per level")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--workload", default=None, choices=["C1", "C2", "C3", "C4", "C5"],
@@ -368,7 +364,7 @@ def main():
     ingest = None
     if args.ingest == "pinned":
         from facerecognition_infrenceengine_amd.ingest import FrameIngest
-        ingest = FrameIngest(FRAMES, H, W, device, depth=args.depth + max(args.embed_group, 1) + args.ingest_ahead, chunks=args.ingest_chunks, streams=args.ingest_streams)
+        ingest = FrameIngest(FRAMES, H, W, device, depth=args.depth + max(args.embed_group, 1) + args.ingest_ahead)
         for k in range(ingest.depth):       # what the capture side would have written
             ingest.host_buffer(k)[...] = batches[k % nbatch].cpu().numpy()
 
@@ -378,10 +374,6 @@ def main():
     app.det.one_stream = args.one_stream        # profiling: pyramid levels on one stream too, per-kernel durations add up
     if args.det_sides is not None:
         app.det.level_streams = args.det_sides
-    if args.embed_chunk is not None:
-        app.rec.max_chunk = args.embed_chunk
-    if args.det_level_nms is not None:
-        app.det.merged_level_nms = args.det_level_nms == "merged"
     if args.pipes <= 0:
         args.pipes = 1 if FRAMES >= 16 else 2
     if args.embed_group <= 0:

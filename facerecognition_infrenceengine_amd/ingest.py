@@ -33,14 +33,12 @@ def decode_image(data):
 class FrameIngest:
     """Ring of ``depth`` batch slots: pinned ``uint8 [N,H,W,3]`` host buffers + matching device buffers."""
 
-    def __init__(self, n, h, w, device="cuda:0", depth=3, chunks=1, streams=1):
-        """``chunks`` / ``streams``: a slot's copy is issued as ``chunks`` frame groups dealt over ``streams`` copy streams
-        (1 / 1: one copy of the whole batch)."""
+    def __init__(self, n, h, w, device="cuda:0", depth=3):
+        """One asynchronous copy of the whole batch per slot on one copy stream (round 4 measured frame groups and a second copy
+        stream: no gain / -5 %, profiles/r04_ingest_ab.txt; the knobs are gone)."""
         _lib.require_gpu()
         self.device = torch.device(device)
         self.shape, self.depth = (int(n), int(h), int(w), 3), int(depth)
-        self.chunks = max(1, min(int(chunks), int(n)))
-        self._extra = [torch.cuda.Stream(device=self.device) for _ in range(max(int(streams), 1) - 1)]
         self._host = [torch.empty(self.shape, dtype=torch.uint8).pin_memory() for _ in range(self.depth)]
         self._dev = [torch.empty(self.shape, dtype=torch.uint8, device=self.device) for _ in range(self.depth)]
         self._stream = torch.cuda.Stream(device=self.device)
@@ -63,20 +61,10 @@ class FrameIngest:
         """Start the H2D copy of the slot; returns (device frames, event that fires when they have landed).
         The copy waits for the slot's previous consumer (see ``release``)."""
         k = slot % self.depth
-        lanes = [self._stream] + self._extra
-        n = self.shape[0]
-        step = -(-n // self.chunks)
-        for li, st in enumerate(lanes):
-            with torch.cuda.stream(st):
-                if self._busy[k] is not None:
-                    st.wait_event(self._busy[k])
-                for c, f0 in enumerate(range(0, n, step)):
-                    if c % len(lanes) == li:
-                        self._dev[k][f0:f0 + step].copy_(self._host[k][f0:f0 + step], non_blocking=True)
-        for st in self._extra:                       # the slot has landed when every lane's share has
-            e = torch.cuda.Event()
-            e.record(st)
-            self._stream.wait_event(e)
+        with torch.cuda.stream(self._stream):
+            if self._busy[k] is not None:
+                self._stream.wait_event(self._busy[k])
+            self._dev[k].copy_(self._host[k], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(self._stream)
         return self._dev[k], ev

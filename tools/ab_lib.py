@@ -31,6 +31,30 @@ elif what == "stage14":
         return lib.fr_conv_stage14_f16(P(x.data_ptr()), P(y.data_ptr()), P(st["w"].data_ptr()), P(st["prm"].data_ptr()), B, st["n"], P(torch.cuda.current_stream().cuda_stream))
     flops = 2.0 * B * 196 * 256 * 2304 * 2 * st["n"]
     base.fr_conv_stage14_f16.argtypes = sig; base.fr_conv_stage14_f16.restype = I
+elif what in ("crop_r", "crop_o"):
+    # fr_crop_conv1_split (conv on the f16 matrix cores) over 64 x 1080p frames with every slot holding a random square box
+    import bench
+    from facerecognition_infrenceengine_amd import FaceAnalysis
+    import warnings
+    warnings.simplefilter("ignore")
+    net_id = 0 if what == "crop_r" else 1
+    det = FaceAnalysis(name="synthetic", arch="r100", cap_o=4).prepare(ctx_id=0).det
+    frames = bench.synth_frames(64, 1080, 1920, 0, torch.device("cuda:0"))
+    cap = 512 if net_id == 0 else 64
+    side = torch.rand((64, cap), generator=g, device="cuda") * 180 + 20
+    cx = torch.rand((64, cap), generator=g, device="cuda") * 1900
+    cy = torch.rand((64, cap), generator=g, device="cuda") * 1060
+    boxes = torch.stack([cx - side / 2, cy - side / 2, cx + side / 2, cy + side / 2], -1).contiguous()
+    counts = torch.full((64,), cap, dtype=torch.int32, device="cuda")
+    w1, b1, s1 = det._rc1 if net_id == 0 else det._oc1
+    p1 = 11 if net_id == 0 else 23
+    x0 = torch.zeros((64 * cap, p1 * p1, 128), dtype=torch.uint8, device="cuda")
+    sig = [I, P, I, I, I, P, P, I, P, P, P, P, I, P]
+    def call(lib, x, y):
+        return lib.fr_crop_conv1_split(net_id, P(frames.data_ptr()), 64, 1080, 1920, P(boxes.data_ptr()), P(counts.data_ptr()), cap,
+                                       P(w1.data_ptr()), P(b1.data_ptr()), P(s1.data_ptr()), P(y.data_ptr()), 1, P(torch.cuda.current_stream().cuda_stream))
+    flops = 1.0
+    base.fr_crop_conv1_split.argtypes = sig; base.fr_crop_conv1_split.restype = I
 else:
     raise SystemExit("unknown entry")
 outs = {}
