@@ -139,7 +139,7 @@ class MTCNNHIP:
         self._tls = threading.local()      # per-thread launch stream: detect_batch is re-entrant across threads
         self.one_stream = False            # True (profiling): every pyramid level on the caller's stream, per-kernel times add up
         self.level_streams = 2             # side streams the pyramid levels 1.. are dealt over (detect_batch's default; round 4: 2 - see detect_batch)
-        self.single_frame_level_streams = self.SINGLE_FRAME_LEVEL_STREAMS      # the same for batches of < 8 frames (0: as level_streams)
+        self.single_frame_level_streams = self.SINGLE_FRAME_LEVEL_STREAMS      # the same for calls of <= solo_max_frames frames (0: as level_streams)
         self.phase_marks = None            # tools: a list -> (name, event on the caller's stream) at the cascade's phase ends
         self.merged_level_nms = True       # the per-level NMS of ALL levels as one launch behind the pyramid (False: one per level)
         # From this many PIXELS per call (frames x H x W) the BATCH arithmetic runs: the band-only exact P-Net pass, P-Net conv1 /
@@ -165,7 +165,7 @@ class MTCNNHIP:
         self._p23 = tuple(t.to(torch.float32).contiguous().to(d) for t in (
             w2p, p["conv2.bias"], p["prelu2.weight"], w3p, p["conv3.bias"], p["prelu3.weight"], hw.t().contiguous(), hb))
         self.refine_margin = 2e-3           # in logit units, ~200x the split-precision error
-        # Batches of >= 8 frames: only the cells within ``refine_margin`` of the face threshold are re-evaluated exactly (every
+        # The batch path (batch_min_pixels): only the cells within ``refine_margin`` of the face threshold are re-evaluated exactly (every
         # keep / reject decision is that of f32 arithmetic); kept cells above the band carry the split-precision heads (~2e-6 from
         # the f32 ones) - as the R-/O-Net crops do (``split_ro``).  False: every cell that can be kept carries the f32 path's bits.
         self.pnet_band = True
@@ -184,7 +184,7 @@ class MTCNNHIP:
             r["conv1.weight"].permute(2, 3, 1, 0).reshape(27, 28), r["conv1.bias"], r["prelu1.weight"]))
         self._oc1 = tuple(t.to(torch.float32).contiguous().to(d) for t in (
             o["conv1.weight"].permute(2, 3, 1, 0).reshape(27, 32), o["conv1.bias"], o["prelu1.weight"]))
-        # second R-/O-Net layer on the f16 matrix cores with split-precision operands (csrc/ro_conv2.hip; batches of >= 8 frames):
+        # second R-/O-Net layer on the f16 matrix cores with split-precision operands (csrc/ro_conv2.hip; the batch path):
         # weights as [cout][tap][32 channels] f32; the crops whose logit lies within ``ro_margin`` of the stage threshold are
         # re-evaluated by the all-f32 layers, so every keep / reject decision is that of f32 arithmetic
         self.split_ro = True
