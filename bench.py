@@ -249,6 +249,9 @@ def main():
                     help="pinned ingest: a step's upload is issued this many steps before the step itself is enqueued (the capture side hands a "
                          "batch over when its ring slot is full, not when the GPU asks for it).  Measured, same box (tools/ab_ingest.sh): resident "
                          "22 940 faces/s; pinned, ahead 0 / 1 / 2: 20 300 / 21 360 / 21 560; 4 frame groups on 1 / 2 copy streams: no gain / -5 %%")
+    ap.add_argument("--frames", type=int, default=0,
+                    help="side measurement: frames per step instead of the workload's own (C2: 64) - the serving curve of latency against "
+                         "throughput by batch size (profiles/r05_batch_size_curve.txt); config.workload states the number used")
     ap.add_argument("--gallery-rows", type=int, default=0, help="override the gallery size (C4: 1 000 000 rows in total)")
     ap.add_argument("--gallery", default="f32", choices=["f32", "f16", "f8"],
                     help="f16 / f8: one-pass coarse scan of a 16- / 8-bit copy on the f16 / fp8 matrix cores + exact f32 "
@@ -285,6 +288,8 @@ def main():
         FRAMES, H, W, FACES_PER_FRAME, GALLERY_ROWS = 1, 480, 640, 1, 100
     elif args.workload == "C3":
         FRAMES, H, W, FACES_PER_FRAME = 8, 2160, 3840, 16
+    if args.frames > 0:
+        FRAMES = args.frames
     world_env = int(os.environ.get("WORLD_SIZE", str(max(args.gpus, 1))))
     if args.workload == "C5":           # 10 M rows over 8 GPUs; fewer ranks keep the per-GPU shard (1.25 M rows)
         GALLERY_ROWS = 1_250_000 * world_env
